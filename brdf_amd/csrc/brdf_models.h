@@ -1,0 +1,170 @@
+// brdf_models.h -- the BRDF models as per-sample device functions.
+//
+// Replaces the reference's BRDFFunc callback (brdfdata.cpp:969-989), which levmar invokes once per
+// evaluation over all n samples.  Here a model is split into the pieces a fused pass needs:
+//
+//     f(p; sample) = combine( lin(p), c0, shape( nl(p), sample ) )
+//
+//   lin(p)   two scalars that enter f linearly           (uniform per pass)
+//   nl(p)    scalars feeding the per-sample transcendental (uniform per pass; depends on p[2] only)
+//   shape    the one transcendental per sample: pow (Phong, Blinn-Phong) / exp (Ward)
+//
+// A forward-difference Jacobian needs f at p and at p+d_j e_j (misc_core.c:153-171).  Because lin()
+// depends on p[0],p[1] (and p[2] for Phong) while nl() depends on p[2] only, the four evaluations
+// share two shape() calls; every value is still bit-identical to evaluating f four times, since each
+// evaluation performs the same operations on the same operands in the same order.
+//
+// Plane layout (struct extraData, brdfdata.cpp:962-966): c0 = cos(L.N), c1 = cos(N.H),
+// c2 = cos(R.V) [Phong] or cos(N.V) [Ward].
+//
+// Model ids: 0 Phong, 1 Blinn-Phong (reference, brdfdata.h:44); 2 Ward (build-defined extension,
+// SURVEY.md section 8 row a3 -- not present in the reference).
+#pragma once
+
+#include <math.h>
+
+#include "lm_machine.h"
+
+namespace brdf {
+
+constexpr double kPi = 3.1415926535897932384626433832795;  // the reference's CV_PI literal
+
+enum ModelId : int { MODEL_PHONG = 0, MODEL_BLINN_PHONG = 1, MODEL_WARD = 2, MODEL_COUNT = 3 };
+
+struct Lin {
+  double a, b;
+};
+struct Nl {
+  double u0, u1;
+};
+
+template <int MODEL>
+struct BrdfModel;
+
+// Phong: x = p0*c0 + ((p2+2)/2*PI)*p1*pow(c2,p2)          brdfdata.cpp:981 (note: *PI, not /(2PI))
+template <>
+struct BrdfModel<MODEL_PHONG> {
+  static constexpr bool uses_c1 = false, uses_c2 = true;
+  static LM_HD Lin lin(const double *p) { return Lin{p[0], ((p[2] + 2.0) / 2.0 * kPi) * p[1]}; }
+  static LM_HD Nl nl(const double *p) { return Nl{p[2], 0.0}; }
+  static LM_HD double shape(const Nl &u, double, double, double c2) { return pow(c2, u.u0); }
+  static LM_HD double combine(const Lin &l, double c0, double s) { return l.a * c0 + l.b * s; }
+};
+
+// Blinn-Phong: x = p0*c0 + p1*pow(c1,p2)                    brdfdata.cpp:986
+template <>
+struct BrdfModel<MODEL_BLINN_PHONG> {
+  static constexpr bool uses_c1 = true, uses_c2 = false;
+  static LM_HD Lin lin(const double *p) { return Lin{p[0], p[1]}; }
+  static LM_HD Nl nl(const double *p) { return Nl{p[2], 0.0}; }
+  static LM_HD double shape(const Nl &u, double, double c1, double) { return pow(c1, u.u0); }
+  static LM_HD double combine(const Lin &l, double c0, double s) { return l.a * c0 + l.b * s; }
+};
+
+// Ward (isotropic): x = c0*( p0/PI + p1 * exp(-tan^2(th_h)/p2^2) / (4 PI p2^2 sqrt(c0 c2)) )
+template <>
+struct BrdfModel<MODEL_WARD> {
+  static constexpr bool uses_c1 = true, uses_c2 = true;
+  static LM_HD Lin lin(const double *p) { return Lin{p[0] / kPi, p[1]}; }
+  static LM_HD Nl nl(const double *p) {
+    const double a2 = p[2] * p[2];
+    return Nl{a2, 1.0 / (4.0 * kPi * a2)};
+  }
+  static LM_HD double shape(const Nl &u, double c0, double c1, double c2) {
+    const double ch2 = c1 * c1;
+    const double t2 = (1.0 - ch2) / ch2;
+    const double g = exp(-t2 / u.u0);
+    return u.u1 * g / sqrt(c0 * c2);
+  }
+  static LM_HD double combine(const Lin &l, double c0, double s) { return c0 * (l.a + l.b * s); }
+};
+
+// ---- per-pass uniforms derived from a Request<3> ---------------------------------------------------
+constexpr int kM = 3;  // {kd, ks, n} / {rho_d, rho_s, alpha}: brdfdata.cpp:1046, :1107
+
+template <int MODEL>
+struct PassUniforms {
+  using Mdl = BrdfModel<MODEL>;
+  Lin l0;           // at p
+  Nl n0;            // at p
+  Lin lp[kM];       // at p + d_j e_j
+  Lin lm[kM];       // at p - d_j e_j           (central differences)
+  Nl np2, nm2;      // at p[2] + d_2, p[2] - d_2
+  double dinv[kM];  // 1/d_j (forward) or 0.5/d_j (central): misc_core.c:167, :206
+  Lin lq;           // at q                       (dif trial)
+  Nl nq;
+  double dp[kM], dp_l2, scal;
+  int central;
+
+  LM_HD void build(const Request<kM> &r) {
+    l0 = Mdl::lin(r.p);
+    n0 = Mdl::nl(r.p);
+    central = r.central;
+    scal = r.scal;
+    dp_l2 = r.dp_l2;
+    for (int j = 0; j < kM; ++j) dp[j] = r.dp[j];
+    if (r.kind == RQ_JAC || r.kind == RQ_DIF_JAC) {
+      for (int j = 0; j < kM; ++j) {
+        double pp[kM] = {r.p[0], r.p[1], r.p[2]};
+        pp[j] = r.p[j] + r.d[j];  // "p[j]+=d", misc_core.c:161 / "tmp+d", :202
+        lp[j] = Mdl::lin(pp);
+        if (j == kM - 1) np2 = Mdl::nl(pp);
+        double pm[kM] = {r.p[0], r.p[1], r.p[2]};
+        pm[j] = r.p[j] - r.d[j];  // "p[j]-=d", misc_core.c:199
+        lm[j] = Mdl::lin(pm);
+        if (j == kM - 1) nm2 = Mdl::nl(pm);
+        dinv[j] = (r.central ? 0.5 : 1.0) / r.d[j];
+      }
+    }
+    if (r.kind == RQ_DIF_TRIAL) {
+      lq = Mdl::lin(r.q);
+      nq = Mdl::nl(r.q);
+    }
+  }
+};
+
+// f(p) for one sample
+template <int MODEL>
+LM_HD double model_value(const PassUniforms<MODEL> &u, double c0, double c1, double c2) {
+  using Mdl = BrdfModel<MODEL>;
+  return Mdl::combine(u.l0, c0, Mdl::shape(u.n0, c0, c1, c2));
+}
+
+// f(q) for one sample (dif trial point)
+template <int MODEL>
+LM_HD double model_value_q(const PassUniforms<MODEL> &u, double c0, double c1, double c2) {
+  using Mdl = BrdfModel<MODEL>;
+  return Mdl::combine(u.lq, c0, Mdl::shape(u.nq, c0, c1, c2));
+}
+
+// f(p) and one row of the finite-difference Jacobian.  `base` is the value subtracted in the forward
+// formula: f(p) recomputed (bc_dif, lmbc_core.c:1049) or the stored hx (dif, lm_core.c:580).
+template <int MODEL>
+LM_HD void model_fd_row(const PassUniforms<MODEL> &u, double c0, double c1, double c2, bool need_f0,
+                        double &f0, double base_or_nan, bool use_base, double *jrow) {
+  using Mdl = BrdfModel<MODEL>;
+  const double s0 = Mdl::shape(u.n0, c0, c1, c2);
+  if (need_f0) f0 = Mdl::combine(u.l0, c0, s0);
+  const double sp = Mdl::shape(u.np2, c0, c1, c2);
+  if (!u.central) {
+    const double base = use_base ? base_or_nan : f0;
+    jrow[0] = (Mdl::combine(u.lp[0], c0, s0) - base) * u.dinv[0];
+    jrow[1] = (Mdl::combine(u.lp[1], c0, s0) - base) * u.dinv[1];
+    jrow[2] = (Mdl::combine(u.lp[2], c0, sp) - base) * u.dinv[2];
+  } else {
+    const double sm = Mdl::shape(u.nm2, c0, c1, c2);
+    jrow[0] = (Mdl::combine(u.lp[0], c0, s0) - Mdl::combine(u.lm[0], c0, s0)) * u.dinv[0];
+    jrow[1] = (Mdl::combine(u.lp[1], c0, s0) - Mdl::combine(u.lm[1], c0, s0)) * u.dinv[1];
+    jrow[2] = (Mdl::combine(u.lp[2], c0, sp) - Mdl::combine(u.lm[2], c0, sm)) * u.dinv[2];
+  }
+}
+
+// Broyden rank-one update of one Jacobian row, lm_core.c:760-766
+LM_HD void broyden_row(const double *jold, double wrk, double hx, const double *dp, double dp_l2, double *jnew) {
+  double t = 0.0;
+  for (int l = 0; l < kM; ++l) t += jold[l] * dp[l];
+  t = (wrk - hx - t) / dp_l2;
+  for (int j = 0; j < kM; ++j) jnew[j] = jold[j] + t * dp[j];
+}
+
+}  // namespace brdf

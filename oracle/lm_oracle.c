@@ -272,6 +272,18 @@ int orc_covar(const double *JtJ, double *C, double sumsq, int m, int n)
   return m;
 }
 
+/* the reference's size switch between the two paths: n*m <= 1024 in dif (lm_core.c:594) but
+ * n*m < 1024 in bc (lmbc_core.c:573).  Exported for the host-side state-machine harness in tests/. */
+void orc_jtj_jte(const double *jac, const double *e, double *jtj, double *jte, int n, int m, int bc_rule)
+{
+  const int nm = n * m;
+  const int small = bc_rule ? (nm < K_BLOCK * K_BLOCK) : (nm <= K_BLOCK * K_BLOCK);
+  if (small)
+    jtj_jte_small(jac, e, jtj, jte, n, m);
+  else
+    jtj_jte_large(jac, e, jtj, jte, n, m);
+}
+
 static double max_diag(const double *jtj, int m)
 {
   double t = -DBL_MAX;

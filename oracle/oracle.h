@@ -48,6 +48,7 @@ void orc_fdif_forward(orc_func_t f, double *p, const double *hx, double *hxx, do
 void orc_fdif_central(orc_func_t f, double *p, double *hxm, double *hxp, double delta,
                       double *jac, int m, int n, void *adata);
 void orc_jtj_blocked(const double *a, double *b, int n, int m);
+void orc_jtj_jte(const double *jac, const double *e, double *jtj, double *jte, int n, int m, int bc_rule);
 int orc_lu_solve(const double *A, const double *B, double *x, int m);
 int orc_covar(const double *JtJ, double *C, double sumsq, int m, int n);
 
