@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py -- BRDF residual-evals/sec on MI355X (BASELINE.json metric), one JSON line on rank 0.
+
+Workload (config.workload): BASELINE.json configs[1] -- a single-material Ward 3-parameter fit over
+1,000,000 synthetic (cos theta_i, cos theta_h, cos theta_o, measured) samples, fitted with the
+reference's dlevmar_dif entry point (levmar.h:112-115); one *step* = one complete fit with the samples
+already resident in HBM.  The same fit through dlevmar_bc_dif (the call the application makes,
+brdfdata.cpp:1119) is reported next to it under "bc_dif".
+
+residual-evals = info[7] * n, levmar's own nfev accounting.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): every rank fits its own material (different
+seed) -- fits are independent, so there is no data-path collective; the fitted parameters + info[] of all
+steps are gathered to rank 0 with ONE RCCL gather at the end of the timed region.  scaling = "weak".
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MODEL, N_SAMPLES = 2, 1_000_000  # Ward, BASELINE.json configs[1]
+BYTES_PER_SAMPLE_PASS = {0: 24, 1: 24, 2: 32}  # 2 (Ward: 3) planes + measurement, fp64
+
+
+def cpu_baseline(method, angles, x, p0, opts, lb, ub, itmax, budget_s=12.0):
+    """The reference's own CPU levmar path (oracle/_ref, compiled from /root/reference in the dev container)
+    or, if that library is absent, our CPU restatement -- timed on ONE host core on the same inputs."""
+    ref_path = os.path.join(ROOT, "oracle", "_ref", "liblevmar_ref.so")
+    if os.path.exists(ref_path):
+        lib, fn, kind = C.CDLL(ref_path), "ref_brdf_fit", "reference"
+    else:
+        lib, fn, kind = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so")), "orc_brdf_fit", "port"
+    D = C.POINTER(C.c_double)
+    flat = np.ascontiguousarray(angles.reshape(-1))
+    o, l, u = (np.array(v, dtype=np.float64) for v in (opts, lb, ub))
+    reps, evals, secs, p, info = 0, 0.0, 0.0, None, None
+    while reps < 1 or (secs < budget_s and reps < 8):
+        p = np.array(p0, dtype=np.float64)
+        info = np.zeros(10)
+        t0 = time.perf_counter()
+        getattr(lib, fn)(method, MODEL, flat.ctypes.data_as(D), x.ctypes.data_as(D), x.size, p.ctypes.data_as(D), itmax,
+                         o.ctypes.data_as(D), l.ctypes.data_as(D), u.ctypes.data_as(D), info.ctypes.data_as(D))
+        secs += time.perf_counter() - t0
+        evals += info[7] * x.size
+        reps += 1
+    return {"value": evals / secs, "unit": "residual-evals/s", "cores": 1, "kind": kind,
+            "sample": f"{reps} x the full {x.size}-sample Ward {'dlevmar_dif' if method == 0 else 'dlevmar_bc_dif'} fit "
+                      f"({secs:.1f} s of CPU time, gcc -O2)"}, p, info
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import brdf_amd
+    from brdf_amd import synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    # each rank owns one material: same generator, different seed -> different planes and noise
+    angles, x, truth = synth.make_single(MODEL, N_SAMPLES, seed=synth.SEED + 7919 * rank)
+    a_dev = torch.from_numpy(angles).to(dev)
+    x_dev = torch.from_numpy(x).to(dev)
+    p0, opts, lb, ub, itmax = synth.P0[MODEL], synth.OPTS, synth.LB, synth.UB, synth.ITMAX
+
+    def run(method, steps, warmup):
+        for _ in range(warmup):
+            brdf_amd.fit_single(method, MODEL, a_dev, x_dev, p0, lb=lb, ub=ub, itmax=itmax, opts=opts)
+        results = torch.zeros((steps, 13), dtype=torch.float64)
+        passes = jac = 0
+        dev_us = 0.0
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()  # same (current) stream the C ABI launches the pass kernels on
+        for s in range(steps):
+            r = brdf_amd.fit_single(method, MODEL, a_dev, x_dev, p0, lb=lb, ub=ub, itmax=itmax, opts=opts)
+            if r.ret < 0:
+                raise RuntimeError(f"fit failed: {brdf_amd.last_error()}")
+            results[s, :3] = torch.from_numpy(r.p)
+            results[s, 3:] = torch.from_numpy(r.info)
+            st = brdf_amd.last_fit_stats()
+            passes += st["passes"]
+            jac += st["jac_passes"]
+            dev_us += st["device_us"]
+        ev1.record()
+        gathered = None
+        if world > 1:  # the one collective of the job: fitted parameters + info[] of every step -> rank 0
+            res_dev = results.to(dev)
+            gathered = [torch.empty_like(res_dev) for _ in range(world)] if rank == 0 else None
+            dist.gather(res_dev, gathered, dst=0)
+            dist.barrier()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        ev_ms = ev0.elapsed_time(ev1)
+        stat = torch.tensor([wall, float(results[:, 10].sum().item()) * N_SAMPLES, ev_ms, float(passes), float(jac), dev_us],
+                            dtype=torch.float64, device=dev)
+        if world > 1:
+            allstat = [torch.empty_like(stat) for _ in range(world)]
+            dist.all_gather(allstat, stat)
+            allstat = torch.stack(allstat).cpu()
+        else:
+            allstat = stat.cpu()[None, :]
+        if rank == 0 and gathered is not None:
+            results = torch.stack([g.cpu() for g in gathered])  # [world, steps, 13]
+        else:
+            results = results[None]
+        return allstat, results
+
+    out = {}
+    for method, name in ((0, "dif"), (1, "bc_dif")):
+        allstat, results = run(method, args.steps, args.warmup)
+        wall = float(allstat[:, 0].max())  # max over ranks
+        evals = float(allstat[:, 1].sum())  # whole job
+        r0 = results[0]
+        out[name] = {
+            "value": evals / wall, "ms_per_step": 1e3 * wall / args.steps, "evals_per_step_rank0": float(r0[0, 10]) * N_SAMPLES,
+            "nfev": float(r0[0, 10]), "iters": float(r0[0, 8]), "passes_per_step": float(allstat[0, 3]) / args.steps,
+            "event_ms_rank0": float(allstat[0, 2]), "device_us_per_step": float(allstat[0, 5]) / args.steps,
+            "p": [float(v) for v in r0[0, :3]], "sumsq": float(r0[0, 4]),
+            "avg_launch_us": 1e3 * float(allstat[0, 2]) / max(1.0, float(allstat[0, 3])),
+        }
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    head = out["dif"]
+    bytes_per_launch = BYTES_PER_SAMPLE_PASS[MODEL] * N_SAMPLES
+    achieved = bytes_per_launch / (head["avg_launch_us"] * 1e-6) / 1e9
+    line = {
+        "metric": "BRDF residual-evals/sec (whole job)", "value": head["value"], "unit": "residual-evals/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "BASELINE.json configs[1]: single-material Ward 3-param fit, 1,000,000 synthetic samples, "
+                               "dlevmar_dif (FD Jacobian + Broyden), p0={0.5,0.5,0.3}, opts={1e-3,1e-15,1e-15,1e-20,1e-6}, itmax=100; "
+                               "one step = one complete fit, samples resident in HBM; one material per GPU",
+                   "n_samples": N_SAMPLES, "model": "ward", "entry_point": "dlevmar_dif", "fits_per_step_per_gpu": 1,
+                   "nfev_per_fit": head["nfev"], "lm_iterations": head["iters"], "passes_per_fit": head["passes_per_step"]},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None,
+                     "kernel": "brdf::stream_pass<2,0> (fused model eval + residual + Broyden + JtJ/Jte sweep, one launch per LM evaluation)",
+                     "algorithmic_bytes_per_launch": bytes_per_launch,
+                     "avg_launch_us": head["avg_launch_us"],
+                     "note": "avg launch = HIP-event time of the timed region / pass launches in it (includes inter-launch gaps and the "
+                             "in-kernel LM state-machine step); 32 B per sample-pass for Ward (3 planes + measurement, fp64)"},
+        "fitted_params": head["p"], "sumsq": head["sumsq"],
+        "bc_dif": {k: out["bc_dif"][k] for k in ("value", "ms_per_step", "nfev", "iters", "passes_per_step", "avg_launch_us", "p")},
+    }
+    if not args.no_cpu:
+        base, p_cpu, info_cpu = cpu_baseline(0, angles, x, p0, opts, lb, ub, itmax)
+        line["cpu_baseline"] = base
+        p_gpu = np.array(head["p"])
+        line["parity"] = {"max_rel_err_params_vs_cpu_levmar": float(np.max(np.abs(p_gpu - p_cpu) / np.maximum(np.abs(p_cpu), 1e-12))),
+                          "rel_err_sumsq": float(abs(head["sumsq"] - info_cpu[1]) / info_cpu[1]), "tolerance": 1e-5}
+        base_bc, p_cpu_bc, _ = cpu_baseline(1, angles, x, p0, opts, lb, ub, itmax, budget_s=6.0)
+        line["bc_dif"]["cpu_baseline"] = base_bc
+        line["bc_dif"]["max_rel_err_params_vs_cpu_levmar"] = float(
+            np.max(np.abs(np.array(out["bc_dif"]["p"]) - p_cpu_bc) / np.maximum(np.abs(p_cpu_bc), 1e-12)))
+    print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

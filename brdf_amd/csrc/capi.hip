@@ -1,0 +1,301 @@
+// capi.hip -- the C ABI of libbrdf_hip.so (include/brdf_levmar.h).
+//
+// Host-side mirror of the reference's solver interface: dlevmar_dif / dlevmar_bc_dif keep the exact
+// levmar.h:112-127 signatures and semantics (return value, info[], NULL-able opts/info/work/covar,
+// stderr diagnostics, LM_ERROR instead of exit()).  Everything n-sized runs in the HIP kernels of
+// stream_fit.hip / batch_fit.hip; there is no CPU evaluation path in this library.
+#include <cstring>
+#include <mutex>
+
+#include "../../include/brdf_levmar.h"
+#include "batch_fit.h"
+#include "stream_fit.h"
+
+namespace brdf {
+int model_eval_run(int model, const double *d_angles, int n, const double *p, double *d_hx, hipStream_t stream);
+}
+
+using namespace brdf;
+
+namespace {
+
+typedef void (*model_func_t)(double *, double *, int, int, void *);
+constexpr int kMaxRegistered = 16;
+model_func_t g_registered[kMaxRegistered] = {nullptr};
+std::mutex g_reg_mutex;
+
+bool is_registered(model_func_t f) {
+  if (f == &BRDFFunc_hip) return true;
+  std::lock_guard<std::mutex> lock(g_reg_mutex);
+  for (int i = 0; i < kMaxRegistered; ++i)
+    if (g_registered[i] == f) return true;
+  return false;
+}
+
+// scoped device buffer
+struct DevBuf {
+  double *ptr = nullptr;
+  ~DevBuf() {
+    if (ptr) (void)hipFree(ptr);
+  }
+  int alloc(size_t count) {
+    hipError_t e = hipMalloc(&ptr, count * sizeof(double));
+    if (e != hipSuccess) {
+      set_error("hipMalloc(%zu doubles) failed: %s", count, hipGetErrorString(e));
+      ptr = nullptr;
+      return -1;
+    }
+    return 0;
+  }
+};
+
+int host_fit(int method, const char *who, model_func_t func, double *p, double *x, int m, int n, double *lb,
+             double *ub, double *dscl, int itmax, double *opts, double *info, double *covar, void *adata) {
+  if (!func || !is_registered(func)) {
+    set_error("%s(): `func` is not a registered BRDF model callback. A host function pointer cannot be "
+              "evaluated on the GPU: call brdf_hip_register_model(func) once (see INTEGRATION.md) or pass "
+              "BRDFFunc_hip",
+              who);
+    return LM_ERROR;
+  }
+  if (m != kM) {
+    set_error("%s(): the BRDF models have exactly 3 parameters (got m=%d)", who, m);
+    return LM_ERROR;
+  }
+  if (n < m) {  // lm_core.c:502-505, lmbc_core.c:440-443
+    set_error("%s(): cannot solve a problem with fewer measurements [%d] than unknowns [%d]", who, n, m);
+    return LM_ERROR;
+  }
+  if (!adata || !p) {
+    set_error("%s(): adata (struct extraData) and p must not be NULL", who);
+    return LM_ERROR;
+  }
+  if (!x) {
+    set_error("%s(): x == NULL (zero measurements) is not supported by the HIP path", who);
+    return LM_ERROR;
+  }
+  const brdf_extra_data *ed = static_cast<const brdf_extra_data *>(adata);
+  if (!ed->angles) {
+    set_error("%s(): extraData.angles is NULL", who);
+    return LM_ERROR;
+  }
+  if (ed->modelInfo < 0 || ed->modelInfo >= MODEL_COUNT) {
+    set_error("%s(): extraData.modelInfo=%d is not a known model (the reference would leave hx unwritten)", who,
+              ed->modelInfo);
+    return LM_ERROR;
+  }
+  DevBuf angles, xs;
+  if (angles.alloc(3 * (size_t)n) || xs.alloc((size_t)n)) return LM_ERROR;
+  // Blinn-Phong never reads plane 3 and the reference's per-surfel caller allocates/fills it
+  // incorrectly (brdfdata.cpp:1095, :1102): only the planes the model reads are copied.
+  const bool need1 = ed->modelInfo != MODEL_PHONG, need2 = ed->modelInfo != MODEL_BLINN_PHONG;
+  hipError_t e = hipMemcpy(angles.ptr, ed->angles, sizeof(double) * n, hipMemcpyHostToDevice);
+  if (e == hipSuccess && need1)
+    e = hipMemcpy(angles.ptr + n, ed->angles + n, sizeof(double) * n, hipMemcpyHostToDevice);
+  if (e == hipSuccess && need2)
+    e = hipMemcpy(angles.ptr + 2 * (size_t)n, ed->angles + 2 * (size_t)n, sizeof(double) * n, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(xs.ptr, x, sizeof(double) * n, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    set_error("%s(): host->device copy failed: %s", who, hipGetErrorString(e));
+    return LM_ERROR;
+  }
+  StreamFitArgs a;
+  a.method = method;
+  a.model = ed->modelInfo;
+  a.d_angles = angles.ptr;
+  a.d_x = xs.ptr;
+  a.n = n;
+  a.p = p;
+  a.lb = lb;
+  a.ub = ub;
+  a.dscl = dscl;
+  a.itmax = itmax;
+  a.opts = opts;
+  a.info = info;
+  a.covar = covar;
+  a.stream = nullptr;
+  const int ret = stream_fit_run(a);
+  (void)hipStreamSynchronize(nullptr);  // run-ahead launches still reference the buffers freed below
+  return ret;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dlevmar_dif(void (*func)(double *, double *, int, int, void *), double *p, double *x, int m, int n, int itmax,
+                double *opts, double *info, double * /*work*/, double *covar, void *adata) {
+  return host_fit(BRDF_METHOD_DIF, "dlevmar_dif", func, p, x, m, n, nullptr, nullptr, nullptr, itmax, opts, info,
+                  covar, adata);
+}
+
+int dlevmar_bc_dif(void (*func)(double *, double *, int, int, void *), double *p, double *x, int m, int n,
+                   double *lb, double *ub, double *dscl, int itmax, double *opts, double *info, double * /*work*/,
+                   double *covar, void *adata) {
+  return host_fit(BRDF_METHOD_BC_DIF, "dlevmar_bc_dif", func, p, x, m, n, lb, ub, dscl, itmax, opts, info, covar,
+                  adata);
+}
+
+int brdf_hip_register_model(void (*func)(double *, double *, int, int, void *)) {
+  if (!func) return -1;
+  std::lock_guard<std::mutex> lock(g_reg_mutex);
+  for (int i = 0; i < kMaxRegistered; ++i)
+    if (g_registered[i] == func) return 0;
+  for (int i = 0; i < kMaxRegistered; ++i)
+    if (!g_registered[i]) {
+      g_registered[i] = func;
+      return 0;
+    }
+  set_error("brdf_hip_register_model(): table full (%d entries)", kMaxRegistered);
+  return -1;
+}
+
+int brdf_hip_unregister_model(void (*func)(double *, double *, int, int, void *)) {
+  std::lock_guard<std::mutex> lock(g_reg_mutex);
+  for (int i = 0; i < kMaxRegistered; ++i)
+    if (g_registered[i] == func) {
+      g_registered[i] = nullptr;
+      return 0;
+    }
+  return -1;
+}
+
+void BRDFFunc_hip(double *p, double *hx, int m, int n, void *adata) {
+  const brdf_extra_data *ed = static_cast<const brdf_extra_data *>(adata);
+  if (!p || !hx || !ed || !ed->angles || m != kM || n <= 0) {
+    set_error("BRDFFunc_hip(): bad arguments");
+    return;
+  }
+  if (ed->modelInfo < 0 || ed->modelInfo >= MODEL_COUNT) return;  // reference: hx left unwritten
+  DevBuf angles, out;
+  if (angles.alloc(3 * (size_t)n) || out.alloc((size_t)n)) return;
+  const bool need1 = ed->modelInfo != MODEL_PHONG, need2 = ed->modelInfo != MODEL_BLINN_PHONG;
+  hipError_t e = hipMemcpy(angles.ptr, ed->angles, sizeof(double) * n, hipMemcpyHostToDevice);
+  if (e == hipSuccess && need1) e = hipMemcpy(angles.ptr + n, ed->angles + n, sizeof(double) * n, hipMemcpyHostToDevice);
+  if (e == hipSuccess && need2)
+    e = hipMemcpy(angles.ptr + 2 * (size_t)n, ed->angles + 2 * (size_t)n, sizeof(double) * n, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    set_error("BRDFFunc_hip(): host->device copy failed: %s", hipGetErrorString(e));
+    return;
+  }
+  if (model_eval_run(ed->modelInfo, angles.ptr, n, p, out.ptr, nullptr) != 0) return;
+  e = hipMemcpy(hx, out.ptr, sizeof(double) * n, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) set_error("BRDFFunc_hip(): device->host copy failed: %s", hipGetErrorString(e));
+}
+
+int brdf_hip_fit_dev(int method, int model, const double *d_angles, const double *d_x, int n, double *p,
+                     const double *lb, const double *ub, const double *dscl, int itmax, const double *opts,
+                     double *info, double *covar, void *stream) {
+  StreamFitArgs a;
+  a.method = method;
+  a.model = model;
+  a.d_angles = d_angles;
+  a.d_x = d_x;
+  a.n = n;
+  a.p = p;
+  a.lb = lb;
+  a.ub = ub;
+  a.dscl = dscl;
+  a.itmax = itmax;
+  a.opts = opts;
+  a.info = info;
+  a.covar = covar;
+  a.stream = static_cast<hipStream_t>(stream);
+  return stream_fit_run(a);
+}
+
+int brdf_hip_fit_batch_dev(int method, int model, const double *d_angles, const double *d_x, int S, int n,
+                           double *d_p, const double *lb, const double *ub, int itmax, const double *opts,
+                           double *d_info, int *d_ret, void *stream) {
+  BatchFitArgs a;
+  a.method = method;
+  a.model = model;
+  a.d_angles = d_angles;
+  a.d_x = d_x;
+  a.S = S;
+  a.n = n;
+  a.d_p = d_p;
+  a.lb = lb;
+  a.ub = ub;
+  a.itmax = itmax;
+  a.opts = opts;
+  a.d_info = d_info;
+  a.d_ret = d_ret;
+  a.stream = static_cast<hipStream_t>(stream);
+  return batch_fit_enqueue(a);
+}
+
+int brdf_hip_fit_batch(int method, int model, const double *angles, const double *x, int S, int n, double *p,
+                       const double *lb, const double *ub, int itmax, const double *opts, double *info, int *ret) {
+  if (!angles || !x || !p || S <= 0 || n <= 0) {
+    set_error("brdf_hip_fit_batch(): bad arguments");
+    return LM_ERROR;
+  }
+  const size_t sn = (size_t)S * n;
+  DevBuf d_angles, d_x, d_p, d_info, d_ret;
+  if (d_angles.alloc(3 * sn) || d_x.alloc(sn) || d_p.alloc(3 * (size_t)S) || d_info.alloc(10 * (size_t)S) ||
+      d_ret.alloc(((size_t)S + 1) / 2 + 1))
+    return LM_ERROR;
+  hipError_t e = hipMemcpy(d_angles.ptr, angles, sizeof(double) * 3 * sn, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_x.ptr, x, sizeof(double) * sn, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_p.ptr, p, sizeof(double) * 3 * S, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    set_error("brdf_hip_fit_batch(): host->device copy failed: %s", hipGetErrorString(e));
+    return LM_ERROR;
+  }
+  int *d_ret_i = reinterpret_cast<int *>(d_ret.ptr);
+  if (brdf_hip_fit_batch_dev(method, model, d_angles.ptr, d_x.ptr, S, n, d_p.ptr, lb, ub, itmax, opts, d_info.ptr,
+                             d_ret_i, nullptr) != 0)
+    return LM_ERROR;
+  e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(p, d_p.ptr, sizeof(double) * 3 * S, hipMemcpyDeviceToHost);
+  if (e == hipSuccess && info) e = hipMemcpy(info, d_info.ptr, sizeof(double) * 10 * S, hipMemcpyDeviceToHost);
+  int *host_ret = ret;
+  int *tmp = nullptr;
+  if (!host_ret) host_ret = tmp = new int[S];
+  if (e == hipSuccess) e = hipMemcpy(host_ret, d_ret_i, sizeof(int) * S, hipMemcpyDeviceToHost);
+  int bad = 0;
+  if (e == hipSuccess)
+    for (int s = 0; s < S; ++s) bad += host_ret[s] < 0;
+  delete[] tmp;
+  if (e != hipSuccess) {
+    set_error("brdf_hip_fit_batch(): %s", hipGetErrorString(e));
+    return LM_ERROR;
+  }
+  return bad;
+}
+
+int brdf_hip_model_eval_dev(int model, const double *d_angles, int n, const double *p, double *d_hx, void *stream) {
+  return model_eval_run(model, d_angles, n, p, d_hx, static_cast<hipStream_t>(stream));
+}
+
+int brdf_hip_synth_dev(int model, unsigned long long seed, long long first, int count, int n,
+                       const double *d_truth, double *d_angles, double *d_x, void *stream) {
+  return synth_enqueue(model, seed, first, count, n, d_truth, d_angles, d_x, static_cast<hipStream_t>(stream));
+}
+
+int brdf_hip_device_count(void) {
+  int c = 0;
+  if (hipGetDeviceCount(&c) != hipSuccess) return 0;
+  return c;
+}
+
+const char *brdf_hip_last_error(void) { return get_error(); }
+
+int brdf_hip_last_fit_stats(long long *passes, long long *jac_passes, long long *eval_passes, double *device_us) {
+  const FitStats s = stream_fit_last_stats();
+  if (passes) *passes = s.passes;
+  if (jac_passes) *jac_passes = s.jac_passes;
+  if (eval_passes) *eval_passes = s.eval_passes;
+  if (device_us) *device_us = s.device_us;
+  return 0;
+}
+
+/* diagnostic builds (-DBRDF_STAMPS) only: cycles per section of the pass kernel, summed over passes */
+int brdf_hip_last_fit_stamps(long long *out8) {
+  const FitStats s = stream_fit_last_stats();
+  for (int k = 0; k < 8; ++k) out8[k] = s.stamps[k];
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,80 @@
+// stream_fit.h -- "streamed" regime: ONE large fit (n ~ 1e4 .. 1e8 samples) spread over the whole chip.
+//
+// Every LM evaluation is one kernel launch (a *pass*) on one stream; the scalar LM state machine
+// (lm_machine.h) is re-executed redundantly at the top of each launch by every workgroup from the
+// previous launch's per-workgroup partial sums, so the launches form a dependency chain with no
+// host round trip and no intra-launch hand-off (the kernel boundary is the only synchronisation:
+// MI355X_MICROARCH "boundary" row, ~1.5 us, cheaper than any grid barrier on this chip).
+#pragma once
+
+#include "device_common.h"
+
+namespace brdf {
+
+constexpr int kStreamThreads = 512;
+constexpr int kStreamMaxBlocks = 512;  // width of the partial-sum rows (and of the folding reduction)
+constexpr int kStreamGridCap = 256;    // workgroups actually launched: one per CU (the pass kernel is
+                                       // register-heavy: 2 waves/SIMD, i.e. one 512-thread workgroup per CU)
+
+union MachineUnion {
+  DifMachine<kM> dif;
+  BcMachine<kM> bc;
+  __host__ __device__ MachineUnion() {}
+};
+
+// pinned, host-mapped: the finishing pass writes the result here (system scope), the host polls `done`
+struct Mailbox {
+  int done;
+  int ret;
+  int passes;
+  int infeasible_mask;
+  long long t_first, t_last;  // s_memrealtime stamps (100 MHz) of the first and the finishing pass
+  long long n_jac, n_eval;
+  double p[kM];
+  double info[kInfoSz];
+  double covar[kM * kM];
+  int progress;  // last pass index that started (run-ahead throttle)
+  int pad;
+  long long stamps[8];  // diagnostic builds only (-DBRDF_STAMPS): cycles per kernel section, summed over passes
+};
+
+struct StreamCtx {
+  const double *c0, *c1, *c2, *x;
+  double *hx[2];   // f(p) at the current / trial point          (dif only)
+  double *jac[2];  // Jacobian, SoA: plane k at jac[b] + k*n     (dif only)
+  double *partials;  // [2][kSlots][kStreamMaxBlocks]
+  Mailbox *mbox;     // device-visible address of the pinned mailbox
+  int n, nb, method, model;
+  int done;  // sticky: set by the finishing pass, read by every later pass
+  int pad0;
+  long long t_first;
+  long long n_jac, n_eval;
+  long long stamps[8];
+  MachineUnion m[2];  // double-buffered: pass k reads m[k&1], writes m[(k+1)&1]
+};
+
+// enqueue-and-wait driver; returns the solver's return value (>=0 iterations, or kLmError)
+struct StreamFitArgs {
+  int method, model;
+  const double *d_angles, *d_x;
+  int n;
+  double *p;
+  const double *lb, *ub, *dscl;
+  int itmax;
+  const double *opts;
+  double *info, *covar;
+  hipStream_t stream;
+};
+int stream_fit_run(const StreamFitArgs &a);
+
+struct FitStats {
+  long long passes, jac_passes, eval_passes;
+  double device_us;
+  long long stamps[8];
+};
+FitStats stream_fit_last_stats();
+
+void set_error(const char *fmt, ...);
+const char *get_error();
+
+}  // namespace brdf

@@ -1,0 +1,495 @@
+// stream_fit.hip -- streamed regime kernels + host driver (see stream_fit.h).
+//
+// Replaces, for one large fit: the per-evaluation model loop (brdfdata.cpp:975-988), e=x-hx / ||e||^2
+// (misc_core.c:721-807), the FD Jacobian fill (misc_core.c:153-171, :191-210), J^T J / J^T e
+// (lm_core.c:617-653, misc_core.c:103-128) and the Broyden update (lm_core.c:760-766), fused into
+// one HBM/L2 sweep per LM evaluation.
+//
+// Data layout in HBM: the caller's SoA planes c0|c1|c2 (n doubles each) and x[n] are read in place,
+// 8 B per lane coalesced.  dif keeps two hx[n] buffers and two SoA Jacobians (3 planes of n) so the
+// trial pass can write the Broyden-updated Jacobian speculatively and the state machine commits by
+// flipping an index.  Workgroup b sweeps one contiguous tile; tiles are dealt so that the eight
+// workgroups {b, b+8, ...} that share an XCD own one contiguous eighth of the arrays, i.e. every
+// XCD's private L2 keeps seeing the same 1/8 slice on every pass.
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <type_traits>
+
+#include "stream_fit.h"
+
+namespace brdf {
+
+// ---------------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------------
+template <int METHOD>
+using MachineOf = typename std::conditional<METHOD == 0, DifMachine<kM>, BcMachine<kM>>::type;
+
+template <int METHOD>
+__device__ __forceinline__ MachineOf<METHOD> *machine_slot(StreamCtx *ctx, int which) {
+  if constexpr (METHOD == 0)
+    return &ctx->m[which].dif;
+  else
+    return &ctx->m[which].bc;
+}
+
+template <int METHOD>
+__device__ void publish_result(StreamCtx *ctx, const MachineOf<METHOD> &sm, int pass) {
+  Mailbox *mb = ctx->mbox;
+  mb->ret = sm.ret;
+  mb->passes = pass;
+  if constexpr (METHOD == 1)
+    mb->infeasible_mask = sm.infeasible_mask;
+  else
+    mb->infeasible_mask = 0;
+  mb->t_first = ctx->t_first;
+  mb->t_last = (long long)wall_clock64();
+  mb->n_jac = ctx->n_jac;
+  mb->n_eval = ctx->n_eval;
+  for (int k = 0; k < 8; ++k) mb->stamps[k] = ctx->stamps[k];
+  for (int i = 0; i < kM; ++i) mb->p[i] = sm.p[i];
+  for (int i = 0; i < kInfoSz; ++i) mb->info[i] = sm.info[i];
+  for (int i = 0; i < kM * kM; ++i) mb->covar[i] = sm.covar[i];
+  ctx->done = 1;
+  __threadfence_system();
+  __hip_atomic_store(&mb->done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+template <int MODEL, int METHOD>
+__global__ __launch_bounds__(kStreamThreads) void stream_pass(StreamCtx *ctx, int pass) {
+  using Machine = MachineOf<METHOD>;
+  using Mdl = BrdfModel<MODEL>;
+  __shared__ Machine sm;
+  __shared__ PassUniforms<MODEL> su;
+  __shared__ double red[reduce_buf_doubles<kStreamThreads>()];
+  __shared__ double sums[kSlots];
+
+  if (ctx->done) return;  // the fit finished in an earlier launch: queued run-ahead launches fall through
+  const int tid = threadIdx.x;
+  const int par = pass & 1;
+#ifdef BRDF_STAMPS
+  long long st_[8]; int sti_ = 0;
+#define STAMP() do { if (blockIdx.x == 0 && tid == 0) st_[sti_++] = clock64(); } while (0)
+#else
+#define STAMP() do {} while (0)
+#endif
+  STAMP();
+
+  {  // machine state -> LDS
+    const unsigned *src = reinterpret_cast<const unsigned *>(machine_slot<METHOD>(ctx, par));
+    unsigned *dst = reinterpret_cast<unsigned *>(&sm);
+    for (int w = tid; w < (int)(sizeof(Machine) / 4); w += kStreamThreads) dst[w] = src[w];
+  }
+  __syncthreads();
+  STAMP();
+
+  if (pass > 0) {  // fold the previous launch's per-workgroup partials and advance the LM state machine
+    const double *part = ctx->partials + (size_t)par * kSlots * kStreamMaxBlocks;
+    const int nb = ctx->nb;
+    switch (sm.req.kind) {
+    case RQ_JAC: fold_rows<SumLayout<kM>::JAC, kStreamThreads>(part, kStreamMaxBlocks, nb, red, sums); break;
+    case RQ_DIF_JAC: fold_rows<SumLayout<kM>::DIF_JAC, kStreamThreads>(part, kStreamMaxBlocks, nb, red, sums); break;
+    case RQ_DIF_TRIAL: fold_rows<SumLayout<kM>::DIF_TRIAL, kStreamThreads>(part, kStreamMaxBlocks, nb, red, sums); break;
+    default: fold_rows<1, kStreamThreads>(part, kStreamMaxBlocks, nb, red, sums); break;
+    }
+    STAMP();
+    if (tid == 0) sm.step(sums, sums[kSums]);
+    __syncthreads();
+    STAMP();
+  }
+
+  const int kind = sm.req.kind;
+  if (kind == RQ_DONE) {
+    if (blockIdx.x == 0 && tid == 0) publish_result<METHOD>(ctx, sm, pass);
+    return;
+  }
+  if (tid == 0) su.build(sm.req);
+  STAMP();
+  if (blockIdx.x == 0) {  // persist the advanced machine for the next launch
+    const unsigned *src = reinterpret_cast<const unsigned *>(&sm);
+    unsigned *dst = reinterpret_cast<unsigned *>(machine_slot<METHOD>(ctx, par ^ 1));
+    for (int w = tid; w < (int)(sizeof(Machine) / 4); w += kStreamThreads) dst[w] = src[w];
+    if (tid == 0) {
+      if (pass == 0) ctx->t_first = (long long)wall_clock64();
+      if (kind == RQ_JAC || kind == RQ_DIF_JAC)
+        ctx->n_jac += 1;
+      else
+        ctx->n_eval += 1;
+      __hip_atomic_store(&ctx->mbox->progress, pass + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  __syncthreads();
+  STAMP();
+
+  // ---- the sweep -----------------------------------------------------------------------------------
+  const int n = ctx->n;
+  const int nb = gridDim.x;
+  int vb = blockIdx.x;  // workgroups b, b+8, .. share an XCD: give each XCD a contiguous run of tiles
+  if ((nb & 7) == 0) vb = (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3);
+  const int tile = (n + nb - 1) / nb;
+  const int begin = vb * tile;
+  const int end = min(n, begin + tile);
+  const double *__restrict__ c0 = ctx->c0;
+  const double *__restrict__ c1 = ctx->c1;
+  const double *__restrict__ c2 = ctx->c2;
+  const double *__restrict__ x = ctx->x;
+  const PassUniforms<MODEL> u = su;
+
+  double acc[kSums];
+#pragma unroll
+  for (int k = 0; k < kSums; ++k) acc[k] = 0.0;
+  double mx = 0.0;
+  double *outp = ctx->partials + (size_t)(par ^ 1) * kSlots * kStreamMaxBlocks;
+
+  switch (kind) {
+  case RQ_EVAL:
+    for (int i = begin + tid; i < end; i += kStreamThreads) {
+      const double f = model_value<MODEL>(u, c0[i], Mdl::uses_c1 ? c1[i] : 0.0, Mdl::uses_c2 ? c2[i] : 0.0);
+      const double e = x[i] - f;
+      acc[0] += e * e;
+      mx = fmax(mx, fabs(e));
+    }
+    STAMP();
+    block_reduce<1, kStreamThreads>(acc, mx, red, sums);
+    break;
+  case RQ_SCALED:
+    for (int i = begin + tid; i < end; i += kStreamThreads) {
+      const double f = model_value<MODEL>(u, c0[i], Mdl::uses_c1 ? c1[i] : 0.0, Mdl::uses_c2 ? c2[i] : 0.0);
+      const double t = (x[i] - f) / u.scal;
+      acc[0] += t * t;
+    }
+    STAMP();
+    block_reduce<1, kStreamThreads>(acc, mx, red, sums);
+    break;
+  case RQ_JAC:
+    for (int i = begin + tid; i < end; i += kStreamThreads) {
+      double f0 = 0.0, j[kM];
+      model_fd_row<MODEL>(u, c0[i], Mdl::uses_c1 ? c1[i] : 0.0, Mdl::uses_c2 ? c2[i] : 0.0, true, f0, 0.0, false, j);
+      const double e = x[i] - f0;
+      acc_normal_eq(j, e, acc, acc + kNL);
+      acc[kNL + kM] += e * e;
+    }
+    STAMP();
+    block_reduce<SumLayout<kM>::JAC, kStreamThreads>(acc, mx, red, sums);
+    break;
+  case RQ_DIF_INIT: {
+    double *__restrict__ hx = ctx->hx[sm.req.sel_hx];
+    for (int i = begin + tid; i < end; i += kStreamThreads) {
+      const double f = model_value<MODEL>(u, c0[i], Mdl::uses_c1 ? c1[i] : 0.0, Mdl::uses_c2 ? c2[i] : 0.0);
+      hx[i] = f;
+      const double e = x[i] - f;
+      acc[0] += e * e;
+    }
+    STAMP();
+    block_reduce<1, kStreamThreads>(acc, mx, red, sums);
+    break;
+  }
+  case RQ_DIF_JAC: {
+    const double *__restrict__ hx = ctx->hx[sm.req.sel_hx];
+    double *__restrict__ jb = ctx->jac[sm.req.sel_j];
+    for (int i = begin + tid; i < end; i += kStreamThreads) {
+      double f0 = 0.0, j[kM];
+      const double h = hx[i];
+      model_fd_row<MODEL>(u, c0[i], Mdl::uses_c1 ? c1[i] : 0.0, Mdl::uses_c2 ? c2[i] : 0.0, false, f0, h, true, j);
+      jb[i] = j[0];
+      jb[(size_t)n + i] = j[1];
+      jb[2 * (size_t)n + i] = j[2];
+      acc_normal_eq(j, x[i] - h, acc, acc + kNL);
+    }
+    STAMP();
+    block_reduce<SumLayout<kM>::DIF_JAC, kStreamThreads>(acc, mx, red, sums);
+    break;
+  }
+  case RQ_DIF_TRIAL: {
+    const double *__restrict__ hx = ctx->hx[sm.req.sel_hx];
+    double *__restrict__ hn = ctx->hx[sm.req.sel_hx ^ 1];
+    const double *__restrict__ jo = ctx->jac[sm.req.sel_j];
+    double *__restrict__ jn = ctx->jac[sm.req.sel_j ^ 1];
+    for (int i = begin + tid; i < end; i += kStreamThreads) {
+      const double w = model_value_q<MODEL>(u, c0[i], Mdl::uses_c1 ? c1[i] : 0.0, Mdl::uses_c2 ? c2[i] : 0.0);
+      const double h = hx[i], xi = x[i];
+      const double jold[kM] = {jo[i], jo[(size_t)n + i], jo[2 * (size_t)n + i]};
+      double j[kM];
+      broyden_row(jold, w, h, u.dp, u.dp_l2, j);
+      hn[i] = w;
+      jn[i] = j[0];
+      jn[(size_t)n + i] = j[1];
+      jn[2 * (size_t)n + i] = j[2];
+      const double en = xi - w, eo = xi - h;
+      acc[0] += en * en;
+      acc_normal_eq(j, en, acc + 1, acc + 1 + kNL);
+      acc[1 + kNL + kM + 0] += j[0] * eo;
+      acc[1 + kNL + kM + 1] += j[1] * eo;
+      acc[1 + kNL + kM + 2] += j[2] * eo;
+    }
+    STAMP();
+    block_reduce<SumLayout<kM>::DIF_TRIAL, kStreamThreads>(acc, mx, red, sums);
+    break;
+  }
+  default: return;
+  }
+
+  if (tid < kSlots) outp[tid * kStreamMaxBlocks + blockIdx.x] = sums[tid];
+  STAMP();
+#ifdef BRDF_STAMPS
+  if (blockIdx.x == 0 && tid == 0 && pass > 0 && sti_ == 8)
+    for (int k = 0; k < 7; ++k) ctx->stamps[k] += st_[k + 1] - st_[k];
+#endif
+}
+
+// K1 alone: hx[i] = f(p; sample i)  (BRDFFunc, brdfdata.cpp:969-989)
+template <int MODEL>
+__global__ __launch_bounds__(256) void model_eval_kernel(const double *__restrict__ c0, const double *__restrict__ c1,
+                                                         const double *__restrict__ c2, int n, Request<kM> r,
+                                                         double *__restrict__ hx) {
+  using Mdl = BrdfModel<MODEL>;
+  PassUniforms<MODEL> u;
+  u.build(r);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    hx[i] = model_value<MODEL>(u, c0[i], Mdl::uses_c1 ? c1[i] : 0.0, Mdl::uses_c2 ? c2[i] : 0.0);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  fprintf(stderr, "libbrdf_hip: %s\n", g_err);
+}
+const char *get_error() { return g_err; }
+
+#define HIP_OK(call)                                                                  \
+  do {                                                                                \
+    hipError_t e_ = (call);                                                           \
+    if (e_ != hipSuccess) {                                                           \
+      set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return kLmError;                                                                \
+    }                                                                                 \
+  } while (0)
+
+namespace {
+
+struct Workspace {
+  int device = -1;
+  StreamCtx *d_ctx = nullptr;
+  StreamCtx *h_ctx = nullptr;  // pinned staging
+  Mailbox *h_mbox = nullptr;   // pinned + mapped
+  Mailbox *d_mbox = nullptr;
+  double *d_partials = nullptr;
+  double *d_dif = nullptr;  // 2*n (hx) + 6*n (two SoA Jacobians)
+  size_t dif_cap = 0;
+  hipStream_t last_stream = nullptr;
+  bool used = false;
+  FitStats stats{};
+
+  int ensure(int dev) {
+    if (device == dev && d_ctx) return 0;
+    release();
+    device = dev;
+    HIP_OK(hipMalloc(&d_ctx, sizeof(StreamCtx)));
+    HIP_OK(hipHostMalloc(&h_ctx, sizeof(StreamCtx), hipHostMallocDefault));
+    HIP_OK(hipHostMalloc(&h_mbox, sizeof(Mailbox), hipHostMallocMapped | hipHostMallocCoherent));
+    HIP_OK(hipHostGetDevicePointer((void **)&d_mbox, h_mbox, 0));
+    HIP_OK(hipMalloc(&d_partials, sizeof(double) * 2 * kSlots * kStreamMaxBlocks));
+    HIP_OK(hipMemset(d_partials, 0, sizeof(double) * 2 * kSlots * kStreamMaxBlocks));
+    return 0;
+  }
+  int ensure_dif(size_t n) {
+    if (dif_cap >= n) return 0;
+    if (d_dif) (void)hipFree(d_dif);
+    d_dif = nullptr;
+    dif_cap = 0;
+    HIP_OK(hipMalloc(&d_dif, sizeof(double) * 8 * n));
+    dif_cap = n;
+    return 0;
+  }
+  void release() {
+    if (d_ctx) (void)hipFree(d_ctx);
+    if (h_ctx) (void)hipHostFree(h_ctx);
+    if (h_mbox) (void)hipHostFree(h_mbox);
+    if (d_partials) (void)hipFree(d_partials);
+    if (d_dif) (void)hipFree(d_dif);
+    d_ctx = nullptr;
+    h_ctx = nullptr;
+    h_mbox = nullptr;
+    d_mbox = nullptr;
+    d_partials = nullptr;
+    d_dif = nullptr;
+    dif_cap = 0;
+  }
+};
+thread_local Workspace g_ws;
+
+using PassFn = void (*)(StreamCtx *, int);
+PassFn pass_kernel(int model, int method) {
+  static const PassFn table[MODEL_COUNT][2] = {
+      {stream_pass<0, 0>, stream_pass<0, 1>},
+      {stream_pass<1, 0>, stream_pass<1, 1>},
+      {stream_pass<2, 0>, stream_pass<2, 1>},
+  };
+  return table[model][method];
+}
+
+int blocks_for(int n) {
+  // ~4 samples per lane; at most 2 workgroups per CU; a multiple of 8 so that the XCD dealing applies
+  long long nb = ((long long)n + kStreamThreads * 4 - 1) / (kStreamThreads * 4);
+  if (nb > kStreamGridCap) nb = kStreamGridCap;
+  if (nb >= 8) nb &= ~7LL;
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
+
+}  // namespace
+
+FitStats stream_fit_last_stats() { return g_ws.stats; }
+
+int stream_fit_run(const StreamFitArgs &a) {
+  if (a.model < 0 || a.model >= MODEL_COUNT) {
+    set_error("unknown BRDF model %d (0 Phong, 1 Blinn-Phong, 2 Ward)", a.model);
+    return kLmError;
+  }
+  if (a.method != 0 && a.method != 1) {
+    set_error("unknown method %d (0 dlevmar_dif, 1 dlevmar_bc_dif)", a.method);
+    return kLmError;
+  }
+  if (!a.p || !a.d_angles || a.n <= 0) {
+    set_error("null parameter vector / sample planes, or n <= 0");
+    return kLmError;
+  }
+  (void)hipGetLastError();  // drop any stale sticky error left by unrelated runtime calls on this thread
+  int dev = 0;
+  HIP_OK(hipGetDevice(&dev));
+  Workspace &ws = g_ws;
+  if (ws.ensure(dev) != 0) return kLmError;
+  if (ws.used && ws.last_stream != a.stream) HIP_OK(hipStreamSynchronize(ws.last_stream));
+  ws.last_stream = a.stream;
+  ws.used = true;
+
+  StreamCtx &h = *ws.h_ctx;
+  // the previous call may still have run-ahead launches queued that read d_ctx; the upload below is
+  // stream-ordered behind them, but the pinned staging copy must not change under an in-flight copy
+  HIP_OK(hipStreamSynchronize(a.stream));
+  memset(&h, 0, sizeof h);
+  h.c0 = a.d_angles;
+  h.c1 = a.d_angles + a.n;
+  h.c2 = a.d_angles + 2 * (size_t)a.n;
+  h.x = a.d_x;
+  h.partials = ws.d_partials;
+  h.mbox = ws.d_mbox;
+  h.n = a.n;
+  h.nb = blocks_for(a.n);
+  h.method = a.method;
+  h.model = a.model;
+
+  if (!a.d_x) {
+    set_error("x == NULL (zero measurement vector) is not supported on the device path");
+    return kLmError;
+  }
+
+  if (a.method == 0) {
+    if (ws.ensure_dif((size_t)a.n) != 0) return kLmError;
+    h.hx[0] = ws.d_dif;
+    h.hx[1] = ws.d_dif + (size_t)a.n;
+    h.jac[0] = ws.d_dif + 2 * (size_t)a.n;
+    h.jac[1] = ws.d_dif + 5 * (size_t)a.n;
+    DifMachine<kM> &m = h.m[0].dif;
+    m.start(a.p, a.n, a.itmax, a.opts, a.covar != nullptr);
+    if (m.req.kind == RQ_DONE) {
+      set_error("dlevmar_dif(): cannot solve a problem with fewer measurements [%d] than unknowns [%d]", a.n, kM);
+      return kLmError;
+    }
+  } else {
+    BcMachine<kM> &m = h.m[0].bc;
+    m.start(a.p, a.n, a.lb, a.ub, a.dscl, a.itmax, a.opts, a.covar != nullptr);
+    if (m.req.kind == RQ_DONE) {
+      switch (m.bad_input) {
+      case 1: set_error("dlevmar_bc_dif(): cannot solve a problem with fewer measurements [%d] than unknowns [%d]", a.n, kM); break;
+      case 2: set_error("dlevmar_bc_dif(): at least one lower bound exceeds the upper one"); break;
+      default: set_error("dlevmar_bc_dif(): scaling constants should be positive"); break;
+      }
+      return kLmError;
+    }
+    for (int i = 0; i < kM; ++i)  // same warning as lmbc_core.c:516-520
+      if (m.infeasible_mask & (1 << i))
+        fprintf(stderr, "Warning: component %d of starting point not feasible in dlevmar_bc_dif()! [%g projected to %g]\n",
+                i, m.p_start[i], m.p[i]);
+  }
+
+  Mailbox &mb = *ws.h_mbox;
+  memset(&mb, 0, sizeof mb);
+  HIP_OK(hipMemcpyAsync(ws.d_ctx, &h, sizeof h, hipMemcpyHostToDevice, a.stream));
+
+  const PassFn fn = pass_kernel(a.model, a.method);
+  const dim3 grid(h.nb), block(kStreamThreads);
+  constexpr int kRunAhead = 6;
+  const long long cap = (long long)(a.itmax > 0 ? a.itmax : 1) * 700 + 64;  // LM + <=150 LS + ~400 PG evals per iteration
+  volatile int *done = &mb.done;
+  volatile int *progress = &mb.progress;
+  long long pass = 0;
+  const auto t0 = std::chrono::steady_clock::now();
+  long long spins = 0;
+  while (!*done) {
+    if (pass - (long long)*progress < kRunAhead) {
+      if (pass >= cap) {
+        set_error("pass budget exhausted (%lld launches) without termination", pass);
+        (void)hipStreamSynchronize(a.stream);
+        return kLmError;
+      }
+      hipLaunchKernelGGL(fn, grid, block, 0, a.stream, ws.d_ctx, (int)pass);
+      ++pass;
+      if ((pass & 63) == 0) HIP_OK(hipGetLastError());
+    } else if ((++spins & 0xFFFF) == 0) {
+      const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (sec > 120.0) {
+        set_error("device did not finish within 120 s (pass %lld, progress %d)", pass, *progress);
+        return kLmError;
+      }
+      HIP_OK(hipGetLastError());
+    }
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  HIP_OK(hipGetLastError());
+
+  for (int i = 0; i < kM; ++i) a.p[i] = mb.p[i];
+  if (a.info)
+    for (int i = 0; i < kInfoSz; ++i) a.info[i] = mb.info[i];
+  if (a.covar)
+    for (int i = 0; i < kM * kM; ++i) a.covar[i] = mb.covar[i];
+  ws.stats.passes = mb.passes;
+  ws.stats.jac_passes = mb.n_jac;
+  ws.stats.eval_passes = mb.n_eval;
+  ws.stats.device_us = (double)(mb.t_last - mb.t_first) / 100.0;  // s_memrealtime ticks at 100 MHz
+  for (int k = 0; k < 8; ++k) ws.stats.stamps[k] = mb.stamps[k];
+  return mb.ret;
+}
+
+int model_eval_run(int model, const double *d_angles, int n, const double *p, double *d_hx, hipStream_t stream) {
+  if (model < 0 || model >= MODEL_COUNT || !d_angles || !d_hx || !p || n <= 0) {
+    set_error("model_eval: bad arguments");
+    return kLmError;
+  }
+  (void)hipGetLastError();
+  Request<kM> r;
+  memset(&r, 0, sizeof r);
+  r.kind = RQ_EVAL;
+  r.scal = 1.0;
+  for (int i = 0; i < kM; ++i) r.p[i] = p[i];
+  int blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  const double *c0 = d_angles, *c1 = d_angles + n, *c2 = d_angles + 2 * (size_t)n;
+  switch (model) {
+  case 0: hipLaunchKernelGGL(model_eval_kernel<0>, dim3(blocks), dim3(256), 0, stream, c0, c1, c2, n, r, d_hx); break;
+  case 1: hipLaunchKernelGGL(model_eval_kernel<1>, dim3(blocks), dim3(256), 0, stream, c0, c1, c2, n, r, d_hx); break;
+  default: hipLaunchKernelGGL(model_eval_kernel<2>, dim3(blocks), dim3(256), 0, stream, c0, c1, c2, n, r, d_hx); break;
+  }
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace brdf

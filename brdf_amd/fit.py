@@ -1,0 +1,126 @@
+"""Python host API over the C ABI: torch CUDA(=HIP) tensors provide the device memory and stream."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from ._lib import D, ExtraData, last_error, lib
+
+MODEL_PHONG, MODEL_BLINN_PHONG, MODEL_WARD = 0, 1, 2
+METHOD_DIF, METHOD_BC_DIF = 0, 1
+
+
+@dataclass
+class FitResult:
+    ret: int  # number of iterations, or -1 (LM_ERROR)
+    p: np.ndarray  # fitted parameters [3]
+    info: np.ndarray  # levmar info[10]
+    covar: np.ndarray | None = None
+
+
+def _dptr(a: np.ndarray | None):
+    return None if a is None else a.ctypes.data_as(D)
+
+
+def _f64(v, size):
+    if v is None:
+        return None
+    a = np.ascontiguousarray(np.asarray(v, dtype=np.float64).reshape(-1))
+    assert a.size == size, f"expected {size} values, got {a.size}"
+    return a
+
+
+def _stream_handle(torch):
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def fit_single(method: int, model: int, angles, x, p0, *, lb=None, ub=None, dscl=None, itmax=100, opts=None,
+               want_covar=False) -> FitResult:
+    """One fit over device-resident samples.  angles: CUDA float64 tensor [3,n] (or [3n]), x: [n].
+
+    Mirrors a dlevmar_dif / dlevmar_bc_dif call (levmar.h:112-127) with the samples already in HBM.
+    """
+    import torch
+    assert angles.is_cuda and x.is_cuda and angles.dtype == torch.float64 and x.dtype == torch.float64
+    angles = angles.contiguous()
+    x = x.contiguous()
+    n = x.numel()
+    assert angles.numel() == 3 * n
+    p = _f64(p0, 3).copy()
+    info = np.zeros(10)
+    covar = np.zeros(9) if want_covar else None
+    lb_a, ub_a, ds_a, op_a = _f64(lb, 3), _f64(ub, 3), _f64(dscl, 3), _f64(opts, 5)
+    with torch.cuda.device(x.device):
+        ret = lib.brdf_hip_fit_dev(method, model, angles.data_ptr(), x.data_ptr(), n, _dptr(p), _dptr(lb_a),
+                                   _dptr(ub_a), _dptr(ds_a), itmax, _dptr(op_a), _dptr(info), _dptr(covar),
+                                   _stream_handle(torch))
+    return FitResult(ret, p, info, None if covar is None else covar.reshape(3, 3))
+
+
+def fit_batch(method: int, model: int, angles, x, p0, *, lb=None, ub=None, itmax=100, opts=None):
+    """S independent fits.  angles: CUDA float64 [S,3,n], x: [S,n], p0: CUDA float64 [S,3] (updated in place).
+
+    Returns (p [S,3], info [S,10], ret [S] int32) as CUDA tensors; asynchronous on the current stream.
+    """
+    import torch
+    assert angles.is_cuda and x.is_cuda and p0.is_cuda
+    S, n = x.shape
+    assert tuple(angles.shape) == (S, 3, n) and tuple(p0.shape) == (S, 3)
+    angles = angles.contiguous()
+    x = x.contiguous()
+    p = p0.contiguous()
+    info = torch.zeros((S, 10), dtype=torch.float64, device=x.device)
+    ret = torch.zeros((S,), dtype=torch.int32, device=x.device)
+    lb_a, ub_a, op_a = _f64(lb, 3), _f64(ub, 3), _f64(opts, 5)
+    with torch.cuda.device(x.device):
+        rc = lib.brdf_hip_fit_batch_dev(method, model, angles.data_ptr(), x.data_ptr(), S, n, p.data_ptr(), _dptr(lb_a),
+                                        _dptr(ub_a), itmax, _dptr(op_a), info.data_ptr(), ret.data_ptr(),
+                                        _stream_handle(torch))
+    if rc != 0:
+        raise RuntimeError(f"brdf_hip_fit_batch_dev failed: {last_error()}")
+    return p, info, ret
+
+
+def model_eval(model: int, angles, p):
+    """hx = model(p; samples) on the device (kernel K1 alone).  angles: CUDA float64 [3,n]."""
+    import torch
+    angles = angles.contiguous()
+    n = angles.numel() // 3
+    hx = torch.empty(n, dtype=torch.float64, device=angles.device)
+    pa = _f64(p, 3)
+    with torch.cuda.device(angles.device):
+        rc = lib.brdf_hip_model_eval_dev(model, angles.data_ptr(), n, _dptr(pa), hx.data_ptr(), _stream_handle(torch))
+    if rc != 0:
+        raise RuntimeError(f"brdf_hip_model_eval_dev failed: {last_error()}")
+    return hx
+
+
+def host_dlevmar(method: int, model: int, angles: np.ndarray, x: np.ndarray, p0, *, lb=None, ub=None, dscl=None,
+                 itmax=100, opts=None, want_covar=False) -> FitResult:
+    """The drop-in call exactly as brdfdata.cpp:1058/1119 makes it: HOST arrays, a BRDFFunc-style callback
+    (here the library's own BRDFFunc_hip) and a struct extraData payload."""
+    angles = np.ascontiguousarray(angles, dtype=np.float64).reshape(-1)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    n = x.size
+    p = _f64(p0, 3).copy()
+    info = np.zeros(10)
+    covar = np.zeros(9) if want_covar else None
+    ed = ExtraData(_dptr(angles), model)
+    func = C.cast(lib.BRDFFunc_hip, C.c_void_p)
+    lb_a, ub_a, ds_a, op_a = _f64(lb, 3), _f64(ub, 3), _f64(dscl, 3), _f64(opts, 5)
+    if method == METHOD_DIF:
+        ret = lib.dlevmar_dif(func, _dptr(p), _dptr(x), 3, n, itmax, _dptr(op_a), _dptr(info), None, _dptr(covar),
+                              C.byref(ed))
+    else:
+        ret = lib.dlevmar_bc_dif(func, _dptr(p), _dptr(x), 3, n, _dptr(lb_a), _dptr(ub_a), _dptr(ds_a), itmax,
+                                 _dptr(op_a), _dptr(info), None, _dptr(covar), C.byref(ed))
+    return FitResult(ret, p, info, None if covar is None else covar.reshape(3, 3))
+
+
+def last_fit_stats() -> dict:
+    a, b, c = C.c_longlong(0), C.c_longlong(0), C.c_longlong(0)
+    us = C.c_double(0.0)
+    lib.brdf_hip_last_fit_stats(C.byref(a), C.byref(b), C.byref(c), C.byref(us))
+    return {"passes": a.value, "jac_passes": b.value, "eval_passes": c.value, "device_us": us.value}

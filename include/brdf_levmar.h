@@ -1,0 +1,122 @@
+/*
+ * brdf_levmar.h -- C ABI of libbrdf_hip.so, the MI355X (gfx950) replacement for the Levenberg-
+ * Marquardt fitting path of ccalantzis/BRDF.
+ *
+ * The boundary is the reference's L3->L4 edge: levmar/levmar.h as it is called from
+ * brdfdata.cpp:1058 and :1119.  Relinking brdfdata.o against this library instead of
+ * levmar/liblevmar.a (BRDF.pro:30) keeps every call site unchanged; see INTEGRATION.md for the one
+ * registration line that lets the library recognise the application's BRDFFunc callback.
+ *
+ * All entry points are plain C: pointers and sizes, no C++/torch types.  Unless a name ends in
+ * `_dev`, pointers are HOST pointers.  Errors never call exit(): they return LM_ERROR (-1) after a
+ * message on stderr, as the reference does for its own argument errors (lm_core.c:502-505,
+ * lmbc_core.c:440-461), and brdf_hip_last_error() returns the text.
+ */
+#ifndef BRDF_LEVMAR_H
+#define BRDF_LEVMAR_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- constants, same values as levmar/levmar.h:68-100 -------------------------------------------- */
+#define LM_DIF_WORKSZ(npar, nmeas) (4 * (nmeas) + 4 * (npar) + (nmeas) * (npar) + (npar) * (npar))
+#define LM_BC_DIF_WORKSZ(npar, nmeas) (2 * (nmeas) + 4 * (npar) + (nmeas) * (npar) + (npar) * (npar))
+#define LM_OPTS_SZ 5
+#define LM_INFO_SZ 10
+#define LM_ERROR (-1)
+#define LM_INIT_MU 1E-03
+#define LM_STOP_THRESH 1E-17
+#define LM_DIFF_DELTA 1E-06
+
+/* adata payload of the BRDF callback: replaces `struct extraData`, brdfdata.cpp:962-966 (same layout).
+ * angles is SoA: [0,n) cos(L.N), [n,2n) cos(N.H), [2n,3n) cos(R.V) (Phong) or cos(N.V) (Ward). */
+struct brdf_extra_data {
+  double *angles;
+  int modelInfo; /* 0 Phong, 1 Blinn-Phong (brdfdata.h:44); 2 Ward (extension, not in the reference) */
+};
+
+enum { BRDF_MODEL_PHONG = 0, BRDF_MODEL_BLINN_PHONG = 1, BRDF_MODEL_WARD = 2 };
+enum { BRDF_METHOD_DIF = 0, BRDF_METHOD_BC_DIF = 1 };
+
+/* ---- drop-in solver entry points ----------------------------------------------------------------- */
+
+/* Replaces dlevmar_dif, levmar/levmar.h:112-115 (body lm_core.c:438-842).  Same arguments, return
+ * value (#iterations or LM_ERROR) and info[0..9] meaning.  `work` is accepted and ignored (the
+ * scratch lives in HBM); nothing is written to it.  `func` must be a registered BRDF callback
+ * (brdf_hip_register_model) or BRDFFunc_hip; m must be 3. */
+int dlevmar_dif(void (*func)(double *p, double *hx, int m, int n, void *adata), double *p, double *x,
+                int m, int n, int itmax, double *opts, double *info, double *work, double *covar,
+                void *adata);
+
+/* Replaces dlevmar_bc_dif, levmar/levmar.h:124-127 (body lmbc_core.c:1062-1129 over :369-1022): the
+ * call the application actually makes.  lb/ub/dscl may be NULL as in the reference; unlike the
+ * reference, lb/ub are never rescaled in place when dscl is given. */
+int dlevmar_bc_dif(void (*func)(double *p, double *hx, int m, int n, void *adata), double *p, double *x,
+                   int m, int n, double *lb, double *ub, double *dscl, int itmax, double *opts,
+                   double *info, double *work, double *covar, void *adata);
+
+/* Declares that `func` has the semantics of the reference's BRDFFunc (brdfdata.cpp:969-989): adata
+ * points to a struct laid out like brdf_extra_data and the value depends on modelInfo.  A host
+ * function pointer cannot run on the GPU; registration is how the drop-in entry points know they
+ * may evaluate the model with the library's own HIP device code instead.  Returns 0, or -1 if the
+ * table (16 entries) is full.  Thread-safe. */
+int brdf_hip_register_model(void (*func)(double *p, double *hx, int m, int n, void *adata));
+int brdf_hip_unregister_model(void (*func)(double *p, double *hx, int m, int n, void *adata));
+
+/* A BRDFFunc-compatible callback evaluated on the GPU (kernel K1 alone): hx[i] = model(p; sample i).
+ * Replaces BRDFFunc, brdfdata.cpp:969-989; always treated as registered. */
+void BRDFFunc_hip(double *p, double *hx, int m, int n, void *adata);
+
+/* ---- device-resident and batched entry points (extensions; the reference has no batched call) ----- */
+
+/* One fit over samples already resident in HBM.  d_angles: 3*n doubles (planes as above), d_x: n
+ * doubles, both DEVICE pointers.  p (in/out, 3), lb/ub/dscl (3 or NULL), opts (5 or NULL), info (10 or
+ * NULL), covar (9 or NULL) are HOST pointers.  stream: a hipStream_t (NULL = default stream).
+ * Returns as dlevmar_dif / dlevmar_bc_dif do. */
+int brdf_hip_fit_dev(int method, int model, const double *d_angles, const double *d_x, int n, double *p,
+                     const double *lb, const double *ub, const double *dscl, int itmax,
+                     const double *opts, double *info, double *covar, void *stream);
+
+/* S independent fits of n samples each -- the loop of CBRDFdata::CalcBRDFEquation
+ * (brdfdata.cpp:1195-1220) as one call.  All array arguments are DEVICE pointers:
+ *   d_angles[S][3][n], d_x[S][n], d_p[S][3] (in: starting points, out: fitted), d_info[S][10] (or NULL),
+ *   d_ret[S] ints (or NULL; per-fit return value).
+ * lb/ub/opts are HOST pointers shared by all fits.  Asynchronous on `stream`; returns 0 on successful
+ * enqueue, LM_ERROR on bad arguments / launch failure. */
+int brdf_hip_fit_batch_dev(int method, int model, const double *d_angles, const double *d_x, int S, int n,
+                           double *d_p, const double *lb, const double *ub, int itmax,
+                           const double *opts, double *d_info, int *d_ret, void *stream);
+
+/* Host-pointer convenience over brdf_hip_fit_batch_dev (uploads, fits, downloads, synchronises).
+ * Returns the number of fits that ended in LM_ERROR, or LM_ERROR itself on argument/HIP errors. */
+int brdf_hip_fit_batch(int method, int model, const double *angles, const double *x, int S, int n,
+                       double *p, const double *lb, const double *ub, int itmax, const double *opts,
+                       double *info, int *ret);
+
+/* hx[i] = model(p; sample i) for device-resident planes; d_hx DEVICE pointer, p HOST pointer. */
+int brdf_hip_model_eval_dev(int model, const double *d_angles, int n, const double *p, double *d_hx,
+                            void *stream);
+
+/* Synthetic sample generator on the device (bench support; bit-identical to brdf_amd/synth.py's
+ * counter stream for the planes).  Fills d_angles[count][3][n], d_x[count][n] for surfels
+ * [first, first+count) with per-surfel truth d_truth[count][3] (device) . */
+int brdf_hip_synth_dev(int model, unsigned long long seed, long long first, int count, int n,
+                       const double *d_truth, double *d_angles, double *d_x, void *stream);
+
+/* ---- diagnostics ----------------------------------------------------------------------------------- */
+int brdf_hip_device_count(void);
+const char *brdf_hip_last_error(void);
+/* counters of the most recent brdf_hip_fit_dev on this thread: passes launched, Jacobian passes,
+ * evaluation passes, device time in microseconds between first and last pass (HIP events). */
+int brdf_hip_last_fit_stats(long long *passes, long long *jac_passes, long long *eval_passes,
+                            double *device_us);
+
+/* only meaningful in diagnostic builds (-DBRDF_STAMPS): shader cycles spent per section of the pass
+ * kernel (load state, fold, step, uniforms, persist, sweep, reduce), summed over the fit's passes. */
+int brdf_hip_last_fit_stamps(long long *out8);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BRDF_LEVMAR_H */

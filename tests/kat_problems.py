@@ -1,0 +1,66 @@
+"""The known-answer problems of the reference's lmdemo.c (starting points, data and bounds as set up in
+lmdemo.c:860-1111; the problem FUNCTIONS themselves are not restated -- they are called by address from the
+compiled reference object in oracle/_ref, which exports them as ordinary symbols)."""
+import ctypes as C
+
+import numpy as np
+
+DM = 1.7976931348623157e308
+OPTS = (1e-3, 1e-15, 1e-15, 1e-20, 1e-6)  # lmdemo.c:816-817
+MEYER_X = [34.780, 28.610, 23.650, 19.630, 16.370, 13.720, 11.540, 9.744, 8.261, 7.030, 6.005, 5.147, 4.427, 3.820,
+           3.307, 2.872]
+
+PROBLEMS = {
+    3: dict(kind="dif", f="wood", p=[-3, -1, -3, -1], x=[0] * 6, itmax=1000),
+    4: dict(kind="dif", f="meyer", p=[8.85, 4.0, 2.5], x=MEYER_X, itmax=1000, covar=True),
+    11: dict(kind="bc_der", f="hs01", j="jachs01", p=[-2, 1], x=[0, 0], lb=[-DM, -1.5], ub=[DM, DM], itmax=1000),
+    12: dict(kind="bc_der", f="hs21", j="jachs21", p=[-1, -1], x=[0, 0], lb=[2, -50], ub=[50, 50], itmax=1000),
+    13: dict(kind="bc_der", f="hatfldb", j="jachatfldb", p=[.1] * 4, x=[0] * 4, lb=[0] * 4, ub=[DM, 0.8, DM, DM],
+             itmax=1000),
+    14: dict(kind="bc_der", f="hatfldc", j="jachatfldc", p=[.9] * 4, x=[0] * 4, lb=[0] * 4, ub=[10] * 4, itmax=1000),
+    15: dict(kind="bc_der", f="combust", j="jaccombust", p=[1e-4] * 5, x=[0] * 5, lb=[1e-4] * 5, ub=[100] * 5,
+             itmax=5000),
+}
+# the same bc problems through the finite-difference shim (not in lmdemo's table; reference-vs-oracle only)
+for _k in (11, 12, 13, 14, 15):
+    _p = dict(PROBLEMS[_k])
+    _p["kind"] = "bc_dif"
+    PROBLEMS[100 + _k] = _p
+
+# what the reference's lmdemo prints ("%.7g" solution; iters, reason, nfev, njev, nlss)
+SURVEY_TABLE = {
+    3: ("1 1 1 1", (113, 6, 158, 11, 113)),
+    4: ("2.481778 6.181346 3.502236", (209, 2, 273, 21, 210)),
+    11: ("1 1", (14, 6, 23, 14, 14)),
+    12: ("2 -4.688186e-19", (5, 1, 10, 6, 5)),
+    13: ("0.9472136 0.8 0.64 0.4096", (939, 2, 3186, 939, 939)),
+    14: ("1 1 1 1", (4, 6, 5, 4, 4)),
+    15: ("0.00343023 31.3265 0.0683504 0.859529 0.03696244", (68, 6, 87, 68, 68)),
+}
+
+
+def run_problem(lib, prefix, pr, ref_lib=None):
+    """Run one problem through `lib` (entry points prefix+dlevmar_*), callbacks taken from ref_lib (default lib)."""
+    from tests.oracle_libs import f64, ptr
+    src = ref_lib or lib
+    fp = lambda name: C.cast(getattr(src, name), C.c_void_p)  # noqa: E731
+    p = f64(pr["p"]).copy()
+    x = f64(pr["x"])
+    m, n = p.size, x.size
+    info = np.zeros(10)
+    opts = f64(OPTS)
+    covar = np.zeros(m * m) if pr.get("covar") else None
+    if pr["kind"] == "dif":
+        fn = getattr(lib, prefix + "dlevmar_dif")
+        r = fn(fp(pr["f"]), ptr(p), ptr(x), m, n, pr["itmax"], ptr(opts), ptr(info), None, ptr(covar), None)
+    else:
+        lb, ub = f64(pr["lb"]), f64(pr["ub"])
+        if pr["kind"] == "bc_der":
+            fn = getattr(lib, prefix + "dlevmar_bc_der")
+            r = fn(fp(pr["f"]), fp(pr["j"]), ptr(p), ptr(x), m, n, ptr(lb), ptr(ub), None, pr["itmax"], ptr(opts),
+                   ptr(info), None, None, None)
+        else:
+            fn = getattr(lib, prefix + "dlevmar_bc_dif")
+            r = fn(fp(pr["f"]), ptr(p), ptr(x), m, n, ptr(lb), ptr(ub), None, pr["itmax"], ptr(opts), ptr(info), None,
+                   None, None)
+    return r, p, info, covar

@@ -1,0 +1,66 @@
+"""ctypes access to the checkers: oracle/liboracle.so (our CPU restatement), oracle/_ref (the reference's
+own levmar compiled from /root/reference, when it was built) and tests/cpp/libhost_machine.so (the product's
+LM state machines driven on the host with reference-order sums).  Test infrastructure only."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+D = C.POINTER(C.c_double)
+
+orc = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+_ref_path = os.path.join(ROOT, "oracle", "_ref", "liblevmar_ref.so")
+ref = C.CDLL(_ref_path) if os.path.exists(_ref_path) else None
+hm = C.CDLL(os.path.join(ROOT, "tests", "cpp", "libhost_machine.so"))
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(D)
+
+
+def f64(v):
+    return None if v is None else np.ascontiguousarray(np.asarray(v, dtype=np.float64).reshape(-1))
+
+
+def brdf_fit(which: str, method: int, model: int, angles, x, p0, itmax=100, opts=None, lb=None, ub=None):
+    """One BRDF fit through the oracle ('orc'), the compiled reference ('ref') or the host-driven product
+    state machine ('hm').  Returns (ret, p[3], info[10])."""
+    a = f64(angles)
+    xx = f64(x)
+    n = xx.size
+    p = f64(p0).copy()
+    info = np.zeros(10)
+    o, l, u = f64(opts), f64(lb), f64(ub)
+    if which == "orc":
+        r = orc.orc_brdf_fit(method, model, ptr(a), ptr(xx), n, ptr(p), itmax, ptr(o), ptr(l), ptr(u), ptr(info))
+    elif which == "ref":
+        assert ref is not None, "oracle/_ref was not built (no /root/reference here and no prebuilt .so)"
+        r = ref.ref_brdf_fit(method, model, ptr(a), ptr(xx), n, ptr(p), itmax, ptr(o), ptr(l), ptr(u), ptr(info))
+    elif which == "hm":
+        r = hm.hm_brdf_fit(method, model, ptr(a), ptr(xx), n, ptr(p), itmax, ptr(o), ptr(l) if method else None,
+                           ptr(u) if method else None, None, ptr(info), None, None)
+    else:
+        raise ValueError(which)
+    return r, p, info
+
+
+def model_values(model: int, angles, p):
+    a = f64(angles)
+    n = a.size // 3
+    hx = np.zeros(n)
+
+    class Extra(C.Structure):
+        _fields_ = [("angles", D), ("modelInfo", C.c_int)]
+
+    ed = Extra(ptr(a), model)
+    pp = f64(p).copy()
+    orc.orc_brdf_func(ptr(pp), ptr(hx), 3, n, C.byref(ed))
+    return hx
+
+
+def rel_err(p, p_ref):
+    p, p_ref = np.asarray(p), np.asarray(p_ref)
+    return float(np.max(np.abs(p - p_ref) / np.maximum(np.abs(p_ref), 1e-12)))

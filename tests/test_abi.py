@@ -1,0 +1,74 @@
+"""The C-ABI library loads and exports every symbol include/brdf_levmar.h declares (no compute without a GPU)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "brdf_levmar.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"^(?:int|void|const char \*)\s*\*?\s*(\w+)\s*\(", text, flags=re.M)
+    return sorted(set(names))
+
+
+def test_header_symbols_are_exported():
+    import brdf_amd
+    declared = _declared_symbols()
+    assert {"dlevmar_dif", "dlevmar_bc_dif", "BRDFFunc_hip", "brdf_hip_fit_dev", "brdf_hip_fit_batch_dev"} <= set(declared)
+    lib = C.CDLL(brdf_amd.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/brdf_levmar.h but not exported"
+    # and the Python binding table covers exactly the header
+    from brdf_amd._lib import ABI
+    assert sorted(ABI) == declared
+
+
+def test_library_is_self_contained_hip_code():
+    """the product must not link the CPU oracle (or the reference) in any form"""
+    import subprocess
+    import brdf_amd
+    out = subprocess.run(["ldd", brdf_amd.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in out and "levmar" not in out
+    assert "amdhip64" in out
+
+
+def test_argument_errors_return_lm_error_without_a_gpu(capfd):
+    """argument validation happens before any HIP call: unregistered callback, m != 3, n < m"""
+    import brdf_amd
+    from brdf_amd._lib import D, ExtraData, MODEL_FUNC, lib
+    angles = np.zeros(30)
+    x = np.zeros(10)
+    p = np.array([0.5, 1.0, 1.0])
+    ed = ExtraData(angles.ctypes.data_as(D), 1)
+
+    @MODEL_FUNC
+    def user_func(p_, hx_, m_, n_, adata_):  # a host callback the library has never been told about
+        pass
+
+    fptr = C.cast(user_func, C.c_void_p)
+    rc = lib.dlevmar_dif(fptr, p.ctypes.data_as(D), x.ctypes.data_as(D), 3, 10, 100, None, None, None, None, C.byref(ed))
+    assert rc == -1 and "not a registered BRDF model" in brdf_amd.last_error()
+    hip = C.cast(lib.BRDFFunc_hip, C.c_void_p)
+    rc = lib.dlevmar_dif(hip, p.ctypes.data_as(D), x.ctypes.data_as(D), 4, 10, 100, None, None, None, None, C.byref(ed))
+    assert rc == -1 and "exactly 3 parameters" in brdf_amd.last_error()
+    rc = lib.dlevmar_bc_dif(hip, p.ctypes.data_as(D), x.ctypes.data_as(D), 3, 2, None, None, None, 100, None, None,
+                            None, None, C.byref(ed))
+    assert rc == -1 and "fewer measurements" in brdf_amd.last_error()
+    assert lib.brdf_hip_register_model(fptr) == 0 and lib.brdf_hip_unregister_model(fptr) == 0
+    assert lib.brdf_hip_unregister_model(fptr) == -1
+    capfd.readouterr()
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    import importlib
+    import brdf_amd._lib as m
+    monkeypatch.setenv("BRDF_HIP_LIB", str(tmp_path / "nope.so"))
+    with pytest.raises(ImportError):
+        importlib.reload(m)
+    monkeypatch.delenv("BRDF_HIP_LIB")
+    importlib.reload(m)

@@ -1,0 +1,109 @@
+"""BRDF fits: the oracle and the host-driven product state machines against the committed fixture that the
+REFERENCE solver produced (tests/golden/brdf_fits.json), bit for bit.  Inputs come from the seeded generator."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from brdf_amd import synth
+from tests import oracle_libs as L
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FITS = json.load(open(os.path.join(HERE, "golden", "brdf_fits.json")))["fits"]
+VALUES = json.load(open(os.path.join(HERE, "golden", "model_values.json")))
+
+
+def _hex(v):
+    return np.array([float.fromhex(s) for s in v])
+
+
+def _id(f):
+    return f"n{f['n']}-model{f['model']}-{'dif' if f['method'] == 0 else 'bc_dif'}"
+
+
+@pytest.mark.parametrize("fit", FITS, ids=_id)
+@pytest.mark.parametrize("which", ["orc", "hm"])
+def test_fit_bit_exact_vs_reference_fixture(which, fit):
+    """'orc' = CPU restatement; 'hm' = the PRODUCT's resumable LM machines + per-sample model math run on the
+    host with reference-order sums.  Both must land on the reference's p / info[] exactly, including iteration,
+    nfev, njev and nlss counts (Broyden bookkeeping, line search and projected-gradient paths are all exercised:
+    nfev up to 1246 on these sets)."""
+    angles, x, _ = synth.make_single(fit["model"], fit["n"])
+    r, p, info = L.brdf_fit(which, fit["method"], fit["model"], angles, x, synth.P0[fit["model"]], synth.ITMAX,
+                            synth.OPTS, synth.LB, synth.UB)
+    assert r == fit["ret"]
+    assert np.array_equal(p, _hex(fit["p"])), (p, _hex(fit["p"]))
+    assert np.array_equal(info, _hex(fit["info"]))
+
+
+@pytest.mark.parametrize("entry", VALUES["values"], ids=lambda e: f"model{e['model']}-p{e['p'][2]}")
+def test_model_values(entry):
+    angles, _, _ = synth.make_single(entry["model"], VALUES["n"])
+    assert np.array_equal(L.model_values(entry["model"], angles, entry["p"]), _hex(entry["hx"]))
+
+
+def test_phong_normalisation_is_times_pi():
+    """brdfdata.cpp:981 multiplies by PI ((n+2)/2*PI); the viewer's (n+2)/(2 PI) is NOT what is fitted"""
+    angles = np.array([0.5, 0.25, 0.75])  # n=1: c0, c1, c2
+    hx = L.model_values(0, angles, [0.2, 0.3, 2.0])
+    assert hx[0] == 0.2 * 0.5 + ((2.0 + 2.0) / 2.0 * synth.PI) * 0.3 * 0.75 ** 2.0
+
+
+def test_unknown_model_leaves_output_untouched():
+    angles = np.array([0.5, 0.25, 0.75])
+    import ctypes as C
+
+    class Extra(C.Structure):
+        _fields_ = [("angles", L.D), ("modelInfo", C.c_int)]
+
+    hx = np.array([123.0])
+    p = np.array([0.2, 0.3, 2.0])
+    L.orc.orc_brdf_func(L.ptr(p), L.ptr(hx), 3, 1, C.byref(Extra(L.ptr(angles), 7)))
+    assert hx[0] == 123.0
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+@pytest.mark.parametrize("n", [3, 5, 17, 100, 257])
+@pytest.mark.parametrize("method", [0, 1])
+def test_machine_bit_exact_vs_oracle_random(seed, n, method):
+    """ragged sizes (n down to m, n%8 != 0) and other seeds: host-driven product machine == oracle"""
+    model = seed % 3
+    angles, x, _ = synth.make_surfels(model, n, first=seed * 1000, count=1, seed=synth.SEED + seed)
+    a = L.brdf_fit("orc", method, model, angles[0], x[0], synth.P0[model], 60, synth.OPTS, synth.LB, synth.UB)
+    b = L.brdf_fit("hm", method, model, angles[0], x[0], synth.P0[model], 60, synth.OPTS, synth.LB, synth.UB)
+    assert a[0] == b[0]
+    assert np.array_equal(a[1], b[1], equal_nan=True) and np.array_equal(a[2], b[2], equal_nan=True)
+
+
+def test_central_differences_and_default_opts():
+    """opts[4] < 0 selects central differences (lm_core.c:514-517, lmbc_core.c:1105); opts == NULL the defaults"""
+    model, n = 1, 200
+    angles, x, _ = synth.make_single(model, n)
+    o = list(synth.OPTS)
+    o[4] = -1e-6
+    for method in (0, 1):
+        a = L.brdf_fit("orc", method, model, angles, x, synth.P0[model], 100, o, synth.LB, synth.UB)
+        b = L.brdf_fit("hm", method, model, angles, x, synth.P0[model], 100, o, synth.LB, synth.UB)
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        a = L.brdf_fit("orc", method, model, angles, x, synth.P0[model], 100, None, synth.LB, synth.UB)
+        b = L.brdf_fit("hm", method, model, angles, x, synth.P0[model], 100, None, synth.LB, synth.UB)
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+
+def test_infeasible_start_is_projected():
+    """lmbc_core.c:514-520: an infeasible p0 is projected into the box (with a warning), not rejected"""
+    model, n = 1, 128
+    angles, x, _ = synth.make_single(model, n)
+    p0 = [-1.0, 150.0, 1.0]
+    a = L.brdf_fit("orc", 1, model, angles, x, p0, 100, synth.OPTS, synth.LB, synth.UB)
+    b = L.brdf_fit("hm", 1, model, angles, x, p0, 100, synth.OPTS, synth.LB, synth.UB)
+    assert a[0] == b[0] >= 0 and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+
+def test_too_few_measurements_is_an_error():
+    """n < m returns LM_ERROR (lm_core.c:502-505, lmbc_core.c:440-443)"""
+    angles, x, _ = synth.make_single(1, 2)
+    for which in ("orc", "hm"):
+        for method in (0, 1):
+            assert L.brdf_fit(which, method, 1, angles, x, synth.P0[1], 10, synth.OPTS, synth.LB, synth.UB)[0] == -1
