@@ -37,6 +37,20 @@ struct Lin {
 struct Nl {
   double u0, u1;
 };
+// Per-sample invariants of the transcendental ("prepared sample").  In the FAST path they are computed
+// once per fit by the first pass and kept in two HBM planes, so that every later evaluation costs one
+// exp per sample instead of a pow (= log + exp) or an exp + two divisions + a square root:
+//   Phong / Blinn-Phong   q1 = log(cos)          pow(c, n) == exp(n * log c)
+//   Ward                  q1 = tan^2(theta_h) = (1 - c1^2)/c1^2 ,  q2 = 1/sqrt(c0*c2)
+// In the EXACT path (FAST = false) q1,q2 are the raw cosines and shape() evaluates the reference's own
+// expression (libm-style pow).  Ward's two paths perform identical operations (the invariants are the
+// same sub-expressions, cached or not) and are bit-identical; for Phong/Blinn-Phong exp(n*log c) differs
+// from pow(c,n) by at most |n log c| * 2^-53 relative on a term that is e^{n log c} small, i.e. below
+// one ulp of the model value -- but it needs c > 0, which domain_ok() checks (the host driver re-runs a
+// fit on the exact path if any used cosine is <= 0).
+struct Prep {
+  double q1, q2;
+};
 
 template <int MODEL>
 struct BrdfModel;
@@ -45,9 +59,14 @@ struct BrdfModel;
 template <>
 struct BrdfModel<MODEL_PHONG> {
   static constexpr bool uses_c1 = false, uses_c2 = true;
+  static constexpr int prep_planes = 1;
   static LM_HD Lin lin(const double *p) { return Lin{p[0], ((p[2] + 2.0) / 2.0 * kPi) * p[1]}; }
   static LM_HD Nl nl(const double *p) { return Nl{p[2], 0.0}; }
-  static LM_HD double shape(const Nl &u, double, double, double c2) { return pow(c2, u.u0); }
+  template <bool FAST>
+  static LM_HD Prep prepare(double, double, double c2) { return Prep{FAST ? log(c2) : c2, 0.0}; }
+  static LM_HD bool domain_ok(double, double, double c2) { return c2 > 0.0; }
+  template <bool FAST>
+  static LM_HD double shape(const Nl &u, double, const Prep &q) { return FAST ? exp(u.u0 * q.q1) : pow(q.q1, u.u0); }
   static LM_HD double combine(const Lin &l, double c0, double s) { return l.a * c0 + l.b * s; }
 };
 
@@ -55,26 +74,41 @@ struct BrdfModel<MODEL_PHONG> {
 template <>
 struct BrdfModel<MODEL_BLINN_PHONG> {
   static constexpr bool uses_c1 = true, uses_c2 = false;
+  static constexpr int prep_planes = 1;
   static LM_HD Lin lin(const double *p) { return Lin{p[0], p[1]}; }
   static LM_HD Nl nl(const double *p) { return Nl{p[2], 0.0}; }
-  static LM_HD double shape(const Nl &u, double, double c1, double) { return pow(c1, u.u0); }
+  template <bool FAST>
+  static LM_HD Prep prepare(double, double c1, double) { return Prep{FAST ? log(c1) : c1, 0.0}; }
+  static LM_HD bool domain_ok(double, double c1, double) { return c1 > 0.0; }
+  template <bool FAST>
+  static LM_HD double shape(const Nl &u, double, const Prep &q) { return FAST ? exp(u.u0 * q.q1) : pow(q.q1, u.u0); }
   static LM_HD double combine(const Lin &l, double c0, double s) { return l.a * c0 + l.b * s; }
 };
 
-// Ward (isotropic): x = c0*( p0/PI + p1 * exp(-tan^2(th_h)/p2^2) / (4 PI p2^2 sqrt(c0 c2)) )
+// Ward (isotropic, build-defined): with a2 = p2^2, t2 = tan^2(theta_h), rinv = 1/sqrt(c0 c2)
+//   x = c0 * ( p0/PI + p1 * ( (1/(4 PI a2)) * exp(-(t2 * (1/a2))) ) * rinv )
+// written with reciprocals so that the per-sample invariants t2 and rinv can be cached.
 template <>
 struct BrdfModel<MODEL_WARD> {
   static constexpr bool uses_c1 = true, uses_c2 = true;
+  static constexpr int prep_planes = 2;
   static LM_HD Lin lin(const double *p) { return Lin{p[0] / kPi, p[1]}; }
   static LM_HD Nl nl(const double *p) {
     const double a2 = p[2] * p[2];
-    return Nl{a2, 1.0 / (4.0 * kPi * a2)};
+    return Nl{1.0 / a2, 1.0 / (4.0 * kPi * a2)};
   }
-  static LM_HD double shape(const Nl &u, double c0, double c1, double c2) {
+  static LM_HD Prep ward_invariants(double c0, double c1, double c2) {
     const double ch2 = c1 * c1;
-    const double t2 = (1.0 - ch2) / ch2;
-    const double g = exp(-t2 / u.u0);
-    return u.u1 * g / sqrt(c0 * c2);
+    return Prep{(1.0 - ch2) / ch2, 1.0 / sqrt(c0 * c2)};
+  }
+  template <bool FAST>
+  static LM_HD Prep prepare(double c0, double c1, double c2) { return FAST ? ward_invariants(c0, c1, c2) : Prep{c1, c2}; }
+  static LM_HD bool domain_ok(double, double, double) { return true; }
+  template <bool FAST>
+  static LM_HD double shape(const Nl &u, double c0, const Prep &q) {
+    const Prep v = FAST ? q : ward_invariants(c0, q.q1, q.q2);
+    const double g = exp(-(v.q1 * u.u0));
+    return (u.u1 * g) * v.q2;
   }
   static LM_HD double combine(const Lin &l, double c0, double s) { return c0 * (l.a + l.b * s); }
 };
@@ -123,36 +157,36 @@ struct PassUniforms {
   }
 };
 
-// f(p) for one sample
-template <int MODEL>
-LM_HD double model_value(const PassUniforms<MODEL> &u, double c0, double c1, double c2) {
+// f(p) for one (prepared) sample
+template <int MODEL, bool FAST>
+LM_HD double model_value(const PassUniforms<MODEL> &u, double c0, const Prep &q) {
   using Mdl = BrdfModel<MODEL>;
-  return Mdl::combine(u.l0, c0, Mdl::shape(u.n0, c0, c1, c2));
+  return Mdl::combine(u.l0, c0, Mdl::template shape<FAST>(u.n0, c0, q));
 }
 
 // f(q) for one sample (dif trial point)
-template <int MODEL>
-LM_HD double model_value_q(const PassUniforms<MODEL> &u, double c0, double c1, double c2) {
+template <int MODEL, bool FAST>
+LM_HD double model_value_q(const PassUniforms<MODEL> &u, double c0, const Prep &q) {
   using Mdl = BrdfModel<MODEL>;
-  return Mdl::combine(u.lq, c0, Mdl::shape(u.nq, c0, c1, c2));
+  return Mdl::combine(u.lq, c0, Mdl::template shape<FAST>(u.nq, c0, q));
 }
 
 // f(p) and one row of the finite-difference Jacobian.  `base` is the value subtracted in the forward
 // formula: f(p) recomputed (bc_dif, lmbc_core.c:1049) or the stored hx (dif, lm_core.c:580).
-template <int MODEL>
-LM_HD void model_fd_row(const PassUniforms<MODEL> &u, double c0, double c1, double c2, bool need_f0,
-                        double &f0, double base_or_nan, bool use_base, double *jrow) {
+template <int MODEL, bool FAST>
+LM_HD void model_fd_row(const PassUniforms<MODEL> &u, double c0, const Prep &q, bool need_f0, double &f0,
+                        double base_or_nan, bool use_base, double *jrow) {
   using Mdl = BrdfModel<MODEL>;
-  const double s0 = Mdl::shape(u.n0, c0, c1, c2);
+  const double s0 = Mdl::template shape<FAST>(u.n0, c0, q);
   if (need_f0) f0 = Mdl::combine(u.l0, c0, s0);
-  const double sp = Mdl::shape(u.np2, c0, c1, c2);
+  const double sp = Mdl::template shape<FAST>(u.np2, c0, q);
   if (!u.central) {
     const double base = use_base ? base_or_nan : f0;
     jrow[0] = (Mdl::combine(u.lp[0], c0, s0) - base) * u.dinv[0];
     jrow[1] = (Mdl::combine(u.lp[1], c0, s0) - base) * u.dinv[1];
     jrow[2] = (Mdl::combine(u.lp[2], c0, sp) - base) * u.dinv[2];
   } else {
-    const double sm = Mdl::shape(u.nm2, c0, c1, c2);
+    const double sm = Mdl::template shape<FAST>(u.nm2, c0, q);
     jrow[0] = (Mdl::combine(u.lp[0], c0, s0) - Mdl::combine(u.lm[0], c0, s0)) * u.dinv[0];
     jrow[1] = (Mdl::combine(u.lp[1], c0, s0) - Mdl::combine(u.lm[1], c0, s0)) * u.dinv[1];
     jrow[2] = (Mdl::combine(u.lp[2], c0, sp) - Mdl::combine(u.lm[2], c0, sm)) * u.dinv[2];

@@ -12,60 +12,75 @@ constexpr int kSums = SumLayout<kM>::MAX;        // 13 reduced sums at most
 constexpr int kSlots = kSums + 1;                // + one max-reduced slot (max |e|)
 constexpr int kNL = SumLayout<kM>::NL;           // 6 lower-triangle entries
 
-// Workgroup reduction of NS sums and one max, as a fixed three-stage tree through LDS (no cross-lane
-// shuffles: a chain of ds_bpermute-based double shuffles costs ~5 us per call on gfx950, this ~0.4 us):
-//   stage 1  every thread stores its NS+1 values            buf[slot][thread]
-//   stage 2  (NS+1)*32 workers each fold THREADS/32 values   stage[slot][32]   (stride-32 walk, in order)
-//   stage 3  NS+1 workers each fold 32 values                out[slot]
-// The order is a pure function of (THREADS, NS): results are reproducible run to run.
-// out[0..NS) receive the sums, out[kSums] the max; visible to all threads on return.
-constexpr int kRedFan = 32;
-constexpr int kRedStride = kRedFan + 1;  // pad: stage-3 workers walk different banks
-
-template <int THREADS>
-constexpr int reduce_buf_doubles() { return kSlots * THREADS + kSlots * kRedStride; }
-
-__device__ __forceinline__ void reduce_stage3(int ns, const double *stage, double *out) {
-  const int t = threadIdx.x;
-  if (t <= ns) {
-    const double *src = stage + t * kRedStride;
-    double s = src[0];
-    if (t < ns) {
-      for (int l = 1; l < kRedFan; ++l) s += src[l];
-      out[t] = s;
-    } else {
-      for (int l = 1; l < kRedFan; ++l) s = fmax(s, src[l]);
-      out[kSums] = s;
-    }
-  }
-  __syncthreads();
+// ---- wave64 reductions on the VALU data-parallel-primitive path (no LDS traffic, no ds_bpermute) --------
+// v_mov_b32_dpp moves a lane's dword to another lane inside the SIMD datapath: row_shr:n shifts inside a
+// row of 16 lanes, row_bcast:15 / row_bcast:31 carry a row's last lane into the following row(s).  Four
+// shift/add steps + two broadcasts leave the sum of all 64 lanes in lane 63 (the classic GCN/CDNA tree).
+// A double is moved as two dwords.  Lanes with no source read `idv` (the identity of the operator).
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ double dpp_move(double v, double idv) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(idv), __double2loint(v), CTRL, ROW_MASK, BANK_MASK, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(idv), __double2hiint(v), CTRL, ROW_MASK, BANK_MASK, false);
+  return __hiloint2double(hi, lo);
 }
+
+struct OpSum {
+  static __device__ __forceinline__ double id() { return 0.0; }
+  static __device__ __forceinline__ double apply(double a, double b) { return a + b; }
+};
+struct OpMax {  // operands are >= 0 here (|e|), so 0 is the identity
+  static __device__ __forceinline__ double id() { return 0.0; }
+  static __device__ __forceinline__ double apply(double a, double b) { return fmax(a, b); }
+};
+
+// result is valid in lane 63 only
+template <class OP>
+__device__ __forceinline__ double wave_reduce_to_last(double v) {
+  v = OP::apply(v, dpp_move<0x111, 0xf, 0xf>(v, OP::id()));  // row_shr:1
+  v = OP::apply(v, dpp_move<0x112, 0xf, 0xf>(v, OP::id()));  // row_shr:2
+  v = OP::apply(v, dpp_move<0x114, 0xf, 0xf>(v, OP::id()));  // row_shr:4
+  v = OP::apply(v, dpp_move<0x118, 0xf, 0xf>(v, OP::id()));  // row_shr:8   -> lane 15 of each row = row total
+  v = OP::apply(v, dpp_move<0x142, 0xa, 0xf>(v, OP::id()));  // row_bcast:15 into rows 1 and 3
+  v = OP::apply(v, dpp_move<0x143, 0xc, 0xf>(v, OP::id()));  // row_bcast:31 into rows 2 and 3 -> lane 63 = total
+  return v;
+}
+
+// Workgroup reduction of NS sums and one max: DPP tree inside each wave, the last lane of every wave
+// parks its value in LDS, NS+1 threads fold the per-wave values in wave order.  Two barriers.  The order
+// is a pure function of (THREADS, NS): results are reproducible run to run.
+// out[0..NS) receive the sums, out[kSums] the max; visible to all threads on return.
+template <int THREADS>
+constexpr int reduce_buf_doubles() { return kSlots * (THREADS / kWave); }
 
 template <int NS, int THREADS>
 __device__ __forceinline__ void block_reduce(const double *acc, double mx, double *buf, double *out) {
-  static_assert((NS + 1) * kRedFan <= THREADS || THREADS >= kRedFan, "worker layout");
-  const int t = threadIdx.x;
-  double *stage = buf + kSlots * THREADS;
+  constexpr int NW = THREADS / kWave;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x >> 6;
 #pragma unroll
-  for (int k = 0; k < NS; ++k) buf[k * THREADS + t] = acc[k];
-  buf[NS * THREADS + t] = mx;
-  __syncthreads();
-  constexpr int PER = THREADS / kRedFan;
-  for (int item = t; item < (NS + 1) * kRedFan; item += THREADS) {
-    const int k = item / kRedFan, l = item % kRedFan;
-    const double *src = buf + k * THREADS + l;
-    double s = src[0];
-    if (k < NS) {
-#pragma unroll
-      for (int j = 1; j < PER; ++j) s += src[j * kRedFan];
-    } else {
-#pragma unroll
-      for (int j = 1; j < PER; ++j) s = fmax(s, src[j * kRedFan]);
-    }
-    stage[k * kRedStride + l] = s;
+  for (int k = 0; k < NS; ++k) {
+    const double v = wave_reduce_to_last<OpSum>(acc[k]);
+    if (lane == kWave - 1) buf[k * NW + wave] = v;
+  }
+  {
+    const double v = wave_reduce_to_last<OpMax>(mx);
+    if (lane == kWave - 1) buf[kSums * NW + wave] = v;
   }
   __syncthreads();
-  reduce_stage3(NS, stage, out);
+  if (threadIdx.x < NS) {
+    const double *src = buf + threadIdx.x * NW;
+    double s = src[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) s += src[w];
+    out[threadIdx.x] = s;
+  } else if (threadIdx.x == kSums) {
+    const double *src = buf + kSums * NW;
+    double s = src[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) s = fmax(s, src[w]);
+    out[kSums] = s;
+  }
+  __syncthreads();
 }
 
 // Same tree over `count` (<= THREADS) per-workgroup partial rows that already sit in global memory:

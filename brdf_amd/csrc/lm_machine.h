@@ -81,14 +81,21 @@ LM_HD bool lm_finite(double v) { return (v - v) == 0.0; }  // false for NaN and 
 
 // Crout LU with implicit row scaling + partial pivoting and the DBL_EPSILON zero-pivot rule, then
 // forward/back substitution: Axb_core.c:1197-1270.  A, B untouched; returns 0 if a row of A is zero.
+// Every array index below is a compile-time constant after unrolling (row exchanges and the
+// permuted right-hand-side picks are written as selects over all candidate rows), so on the GPU the
+// factorisation lives entirely in registers -- no scratch memory, no indirect register access.
 template <int M>
 LM_HD int lu_solve(const double *A, const double *B, double *x) {
   double a[M * M], scale[M];
   int perm[M];
+#pragma unroll
   for (int i = 0; i < M * M; ++i) a[i] = A[i];
+#pragma unroll
   for (int i = 0; i < M; ++i) x[i] = B[i];
+#pragma unroll
   for (int i = 0; i < M; ++i) {
     double big = 0.0;
+#pragma unroll
     for (int j = 0; j < M; ++j) {
       const double t = lm_abs(a[i * M + j]);
       if (t > big) big = t;
@@ -96,16 +103,21 @@ LM_HD int lu_solve(const double *A, const double *B, double *x) {
     if (big == 0.0) return 0;
     scale[i] = 1.0 / big;
   }
+#pragma unroll
   for (int j = 0; j < M; ++j) {
-    int pivot = -1;
+    int pivot = j;
     double big = 0.0;
+#pragma unroll
     for (int i = 0; i < j; ++i) {
       double s = a[i * M + j];
+#pragma unroll
       for (int k = 0; k < i; ++k) s -= a[i * M + k] * a[k * M + j];
       a[i * M + j] = s;
     }
+#pragma unroll
     for (int i = j; i < M; ++i) {
       double s = a[i * M + j];
+#pragma unroll
       for (int k = 0; k < j; ++k) s -= a[i * M + k] * a[k * M + j];
       a[i * M + j] = s;
       const double t = scale[i] * lm_abs(s);
@@ -114,36 +126,52 @@ LM_HD int lu_solve(const double *A, const double *B, double *x) {
         pivot = i;
       }
     }
-    if (pivot < 0) pivot = j;  // only reachable with NaN input; keeps indexing in range
-    if (j != pivot) {
-      for (int k = 0; k < M; ++k) {
-        const double t = a[pivot * M + k];
-        a[pivot * M + k] = a[j * M + k];
-        a[j * M + k] = t;
+    // exchange rows j and pivot (pivot >= j); scale[pivot] <- scale[j]
+#pragma unroll
+    for (int r = j + 1; r < M; ++r) {
+      if (pivot == r) {
+#pragma unroll
+        for (int k = 0; k < M; ++k) {
+          const double t = a[r * M + k];
+          a[r * M + k] = a[j * M + k];
+          a[j * M + k] = t;
+        }
+        scale[r] = scale[j];
       }
-      scale[pivot] = scale[j];
     }
     perm[j] = pivot;
     if (a[j * M + j] == 0.0) a[j * M + j] = DBL_EPSILON;
     if (j != M - 1) {
       const double t = 1.0 / a[j * M + j];
+#pragma unroll
       for (int i = j + 1; i < M; ++i) a[i * M + j] *= t;
     }
   }
   int first = 0;
+#pragma unroll
   for (int i = 0; i < M; ++i) {
-    const int j = perm[i];
-    double s = x[j];
-    x[j] = x[i];
+    // s = x[perm[i]]; x[perm[i]] = x[i];   with perm[i] >= i
+    double s = x[i];
+#pragma unroll
+    for (int r = i + 1; r < M; ++r) {
+      if (perm[i] == r) {
+        s = x[r];
+        x[r] = x[i];
+      }
+    }
     if (first != 0) {
-      for (int jj = first - 1; jj < i; ++jj) s -= a[i * M + jj] * x[jj];
+#pragma unroll
+      for (int jj = 0; jj < i; ++jj)
+        if (jj >= first - 1) s -= a[i * M + jj] * x[jj];
     } else if (s != 0.0) {
       first = i + 1;
     }
     x[i] = s;
   }
+#pragma unroll
   for (int i = M - 1; i >= 0; --i) {
     double s = x[i];
+#pragma unroll
     for (int j = i + 1; j < M; ++j) s -= a[i * M + j] * x[j];
     x[i] = s / a[i * M + i];
   }
@@ -224,259 +252,270 @@ LM_HD FitOptions make_options(const double *opts) {
 template <int M>
 struct DifMachine {
   enum Phase : int { D_INIT_EVAL = 1, D_ITER_TOP, D_AFTER_JAC, D_GRADIENT, D_SOLVE, D_AFTER_TRIAL, D_REJECT, D_FINISH, D_DONE };
-  FitOptions o;
-  int itmax, n, want_covar;
-  int phase, k, stop, nu, nfev, njap, nlss, updjac, updp, newjac, refresh;
-  int sel_hx, sel_j;
-  double p[M], mu, p_e2, init_e2, jte_inf, p_l2, dp_l2, pdp_e2;
-  double jtj[M * M], jte[M], diag[M], dp[M], pdp[M];
-  double spec_jtj[M * M], spec_jte[M];  // normal equations of the Broyden-updated J, adopted lazily
-  double info[kInfoSz], covar[M * M];
-  int ret;
-  Request<M> req;
+  // Cold: configuration and results, touched at start/finish only.  Hot: everything an LM step reads or
+  // writes.  (Measured on gfx950: running the step on a register copy of Hot makes hipcc spill to scratch
+  // and is slower than stepping in place in LDS, so step() works in place.)
+  struct Cold {
+    FitOptions o;
+    int itmax, n, want_covar, refresh;
+    double info[kInfoSz], covar[M * M];
+    int ret;
+  };
+  struct Hot {
+    int phase, k, stop, nu, nfev, njap, nlss, updjac, updp, newjac;
+    int sel_hx, sel_j;
+    double p[M], mu, p_e2, init_e2, jte_inf, p_l2, dp_l2, pdp_e2;
+    double jtj[M * M], jte[M], diag[M], dp[M], pdp[M];
+    double spec_jtj[M * M], spec_jte[M];  // normal equations of the Broyden-updated J, adopted lazily
+    Request<M> req;
+  };
+  Cold c;
+  Hot h;
 
   LM_HD void start(const double *p0, int n_, int itmax_, const double *opts, int want_covar_) {
-    o = make_options(opts);
-    itmax = itmax_;
-    n = n_;
-    want_covar = want_covar_;
-    k = 0;
-    stop = 0;
-    nfev = njap = nlss = 0;
-    updjac = 0;
-    updp = 1;
-    newjac = 0;
-    refresh = (M >= 10) ? M : 10;  // "K", lm_core.c:495
-    sel_hx = sel_j = 0;
-    mu = jte_inf = p_l2 = 0.0;
-    p_e2 = init_e2 = pdp_e2 = 0.0;
-    dp_l2 = DBL_MAX;
-    ret = kLmError;
+    c.o = make_options(opts);
+    c.itmax = itmax_;
+    c.n = n_;
+    c.want_covar = want_covar_;
+    h.k = 0;
+    h.stop = 0;
+    h.nfev = h.njap = h.nlss = 0;
+    h.updjac = 0;
+    h.updp = 1;
+    h.newjac = 0;
+    c.refresh = (M >= 10) ? M : 10;  // "K", lm_core.c:495
+    h.sel_hx = h.sel_j = 0;
+    h.mu = h.jte_inf = h.p_l2 = 0.0;
+    h.p_e2 = h.init_e2 = h.pdp_e2 = 0.0;
+    h.dp_l2 = DBL_MAX;
+    c.ret = kLmError;
     for (int i = 0; i < M; ++i) {
-      p[i] = p0[i];
-      jte[i] = diag[i] = dp[i] = pdp[i] = 0.0;
-      spec_jte[i] = 0.0;
+      h.p[i] = p0[i];
+      h.jte[i] = h.diag[i] = h.dp[i] = h.pdp[i] = 0.0;
+      h.spec_jte[i] = 0.0;
     }
-    for (int i = 0; i < M * M; ++i) jtj[i] = spec_jtj[i] = covar[i] = 0.0;
-    for (int i = 0; i < kInfoSz; ++i) info[i] = 0.0;
-    clear_req();
-    if (n < M) {  // lm_core.c:502-505
-      phase = D_DONE;
-      req.kind = RQ_DONE;
+    for (int i = 0; i < M * M; ++i) h.jtj[i] = h.spec_jtj[i] = c.covar[i] = 0.0;
+    for (int i = 0; i < kInfoSz; ++i) c.info[i] = 0.0;
+    clear_req(h);
+    if (c.n < M) {  // lm_core.c:502-505
+      h.phase = D_DONE;
+      h.req.kind = RQ_DONE;
       return;
     }
-    req.kind = RQ_DIF_INIT;
-    for (int i = 0; i < M; ++i) req.p[i] = p[i];
-    phase = D_INIT_EVAL;
+    h.req.kind = RQ_DIF_INIT;
+    for (int i = 0; i < M; ++i) h.req.p[i] = h.p[i];
+    h.phase = D_INIT_EVAL;
   }
 
-  LM_HD void clear_req() {
-    req.kind = RQ_DONE;
-    req.central = 0;
-    req.sel_hx = sel_hx;
-    req.sel_j = sel_j;
-    req.dp_l2 = 0.0;
-    req.scal = 1.0;
-    for (int i = 0; i < M; ++i) req.p[i] = req.d[i] = req.q[i] = req.dp[i] = 0.0;
+  static LM_HD void clear_req(Hot &h) {
+    h.req.kind = RQ_DONE;
+    h.req.central = 0;
+    h.req.sel_hx = h.sel_hx;
+    h.req.sel_j = h.sel_j;
+    h.req.dp_l2 = 0.0;
+    h.req.scal = 1.0;
+    for (int i = 0; i < M; ++i) h.req.p[i] = h.req.d[i] = h.req.q[i] = h.req.dp[i] = 0.0;
   }
 
-  LM_HD void gradient_stats() {  // lm_core.c:657-662
-    p_l2 = jte_inf = 0.0;
+  static LM_HD void gradient_stats(Hot &h) {  // lm_core.c:657-662
+    h.p_l2 = h.jte_inf = 0.0;
     for (int i = 0; i < M; ++i) {
-      const double t = lm_abs(jte[i]);
-      if (jte_inf < t) jte_inf = t;
-      diag[i] = jtj[i * M + i];
-      p_l2 += p[i] * p[i];
+      const double t = lm_abs(h.jte[i]);
+      if (h.jte_inf < t) h.jte_inf = t;
+      h.diag[i] = h.jtj[i * M + i];
+      h.p_l2 += h.p[i] * h.p[i];
     }
   }
 
-  LM_HD void step(const double *s, double /*maxabs*/) {
+  LM_HD void step(const double *s, double maxabs) { run(c, h, s, maxabs); }
+
+  static LM_HD void run(Cold &c, Hot &h, const double *s, double /*maxabs*/) {
     for (;;) {
-      switch (phase) {
+      switch (h.phase) {
       case D_INIT_EVAL:  // lm_core.c:551-564
-        nfev = 1;
-        p_e2 = s[0];
-        init_e2 = p_e2;
-        if (!lm_finite(p_e2)) stop = 7;
-        nu = 20;
-        phase = D_ITER_TOP;
+        h.nfev = 1;
+        h.p_e2 = s[0];
+        h.init_e2 = h.p_e2;
+        if (!lm_finite(h.p_e2)) h.stop = 7;
+        h.nu = 20;
+        h.phase = D_ITER_TOP;
         break;
 
       case D_ITER_TOP:
-        if (!(k < itmax && !stop)) {
-          phase = D_FINISH;
+        if (!(h.k < c.itmax && !h.stop)) {
+          h.phase = D_FINISH;
           break;
         }
-        if (p_e2 <= o.eps3) {
-          stop = 6;
-          phase = D_FINISH;
+        if (h.p_e2 <= c.o.eps3) {
+          h.stop = 6;
+          h.phase = D_FINISH;
           break;
         }
-        if ((updp && nu > 16) || updjac == refresh) {  // fresh FD Jacobian, lm_core.c:578-588
-          clear_req();
-          req.kind = RQ_DIF_JAC;
-          req.central = !o.forward;
-          for (int i = 0; i < M; ++i) req.p[i] = p[i];
-          fd_steps<M>(p, o.delta, req.d);
-          ++njap;
-          nfev += o.forward ? M : 2 * M;
-          nu = 2;
-          updjac = 0;
-          updp = 0;
-          newjac = 1;
-          phase = D_AFTER_JAC;
+        if ((h.updp && h.nu > 16) || h.updjac == c.refresh) {  // fresh FD Jacobian, lm_core.c:578-588
+          clear_req(h);
+          h.req.kind = RQ_DIF_JAC;
+          h.req.central = !c.o.forward;
+          for (int i = 0; i < M; ++i) h.req.p[i] = h.p[i];
+          fd_steps<M>(h.p, c.o.delta, h.req.d);
+          ++h.njap;
+          h.nfev += c.o.forward ? M : 2 * M;
+          h.nu = 2;
+          h.updjac = 0;
+          h.updp = 0;
+          h.newjac = 1;
+          h.phase = D_AFTER_JAC;
           return;
         }
-        phase = D_GRADIENT;
+        h.phase = D_GRADIENT;
         break;
 
       case D_AFTER_JAC:
-        unpack_lower<M>(s, jtj);
-        for (int i = 0; i < M; ++i) jte[i] = s[SumLayout<M>::NL + i];
-        newjac = 0;
-        gradient_stats();
-        phase = D_SOLVE;
+        unpack_lower<M>(s, h.jtj);
+        for (int i = 0; i < M; ++i) h.jte[i] = s[SumLayout<M>::NL + i];
+        h.newjac = 0;
+        gradient_stats(h);
+        h.phase = D_SOLVE;
         break;
 
       case D_GRADIENT:
-        if (newjac) {  // lm_core.c:590-664 with the sums the trial pass produced for the updated J
-          newjac = 0;
-          for (int i = 0; i < M * M; ++i) jtj[i] = spec_jtj[i];
-          for (int i = 0; i < M; ++i) jte[i] = spec_jte[i];
-          gradient_stats();
+        if (h.newjac) {  // lm_core.c:590-664 with the sums the trial pass produced for the updated J
+          h.newjac = 0;
+          for (int i = 0; i < M * M; ++i) h.jtj[i] = h.spec_jtj[i];
+          for (int i = 0; i < M; ++i) h.jte[i] = h.spec_jte[i];
+          gradient_stats(h);
         }
-        phase = D_SOLVE;
+        h.phase = D_SOLVE;
         break;
 
       case D_SOLVE: {
-        if (jte_inf <= o.eps1) {  // lm_core.c:676-680
-          dp_l2 = 0.0;
-          stop = 1;
-          phase = D_FINISH;
+        if (h.jte_inf <= c.o.eps1) {  // lm_core.c:676-680
+          h.dp_l2 = 0.0;
+          h.stop = 1;
+          h.phase = D_FINISH;
           break;
         }
-        if (k == 0) {  // lm_core.c:683-687
+        if (h.k == 0) {  // lm_core.c:683-687
           double t = -DBL_MAX;
           for (int i = 0; i < M; ++i)
-            if (diag[i] > t) t = diag[i];
-          mu = o.tau * t;
+            if (h.diag[i] > t) t = h.diag[i];
+          h.mu = c.o.tau * t;
         }
-        for (int i = 0; i < M; ++i) jtj[i * M + i] += mu;
-        const int solved = lu_solve<M>(jtj, jte, dp);
-        ++nlss;
+        for (int i = 0; i < M; ++i) h.jtj[i * M + i] += h.mu;
+        const int solved = lu_solve<M>(h.jtj, h.jte, h.dp);
+        ++h.nlss;
         if (!solved) {
-          phase = D_REJECT;
+          h.phase = D_REJECT;
           break;
         }
-        dp_l2 = 0.0;
+        h.dp_l2 = 0.0;
         for (int i = 0; i < M; ++i) {
-          const double t = dp[i];
-          pdp[i] = p[i] + t;
-          dp_l2 += t * t;
+          const double t = h.dp[i];
+          h.pdp[i] = h.p[i] + t;
+          h.dp_l2 += t * t;
         }
-        if (dp_l2 <= o.eps2sq * p_l2) {
-          stop = 2;
-          phase = D_FINISH;
+        if (h.dp_l2 <= c.o.eps2sq * h.p_l2) {
+          h.stop = 2;
+          h.phase = D_FINISH;
           break;
         }
-        if (dp_l2 >= (p_l2 + o.eps2) / (kEpsilon * kEpsilon)) {
-          stop = 4;
-          phase = D_FINISH;
+        if (h.dp_l2 >= (h.p_l2 + c.o.eps2) / (kEpsilon * kEpsilon)) {
+          h.stop = 4;
+          h.phase = D_FINISH;
           break;
         }
-        clear_req();
-        req.kind = RQ_DIF_TRIAL;
+        clear_req(h);
+        h.req.kind = RQ_DIF_TRIAL;
         for (int i = 0; i < M; ++i) {
-          req.p[i] = p[i];
-          req.q[i] = pdp[i];
-          req.dp[i] = dp[i];
+          h.req.p[i] = h.p[i];
+          h.req.q[i] = h.pdp[i];
+          h.req.dp[i] = h.dp[i];
         }
-        req.dp_l2 = dp_l2;
-        ++nfev;
-        phase = D_AFTER_TRIAL;
+        h.req.dp_l2 = h.dp_l2;
+        ++h.nfev;
+        h.phase = D_AFTER_TRIAL;
         return;
       }
 
       case D_AFTER_TRIAL: {  // lm_core.c:742-790
-        pdp_e2 = s[0];
-        if (!lm_finite(pdp_e2)) {
-          stop = 7;
-          phase = D_FINISH;
+        h.pdp_e2 = s[0];
+        if (!lm_finite(h.pdp_e2)) {
+          h.stop = 7;
+          h.phase = D_FINISH;
           break;
         }
-        const double dF = p_e2 - pdp_e2;
-        const bool updated = (updp || dF > 0);
+        const double dF = h.p_e2 - h.pdp_e2;
+        const bool updated = (h.updp || dF > 0);
         if (updated) {  // adopt the speculatively updated Jacobian
-          sel_j ^= 1;
-          ++updjac;
-          newjac = 1;
+          h.sel_j ^= 1;
+          ++h.updjac;
+          h.newjac = 1;
         }
         double dL = 0.0;
-        for (int i = 0; i < M; ++i) dL += dp[i] * (mu * dp[i] + jte[i]);
+        for (int i = 0; i < M; ++i) dL += h.dp[i] * (h.mu * h.dp[i] + h.jte[i]);
         const bool accepted = (dL > 0.0 && dF > 0.0);
         if (updated) {  // keep the updated Jacobian's products, paired with the residual that stays live;
                         // they replace jtj/jte at the top of the next iteration, as in the reference
-          unpack_lower<M>(s + 1, spec_jtj);
+          unpack_lower<M>(s + 1, h.spec_jtj);
           const double *g = s + 1 + SumLayout<M>::NL + (accepted ? 0 : M);
-          for (int i = 0; i < M; ++i) spec_jte[i] = g[i];
+          for (int i = 0; i < M; ++i) h.spec_jte[i] = g[i];
         }
         if (accepted) {
           double t = (2.0 * dF / dL - 1.0);
           t = 1.0 - t * t * t;
-          mu = mu * ((t >= kOneThird) ? t : kOneThird);
-          nu = 2;
-          for (int i = 0; i < M; ++i) p[i] = pdp[i];
-          sel_hx ^= 1;  // e, hx <- trial values
-          p_e2 = pdp_e2;
-          updp = 1;
-          ++k;
-          phase = D_ITER_TOP;
+          h.mu = h.mu * ((t >= kOneThird) ? t : kOneThird);
+          h.nu = 2;
+          for (int i = 0; i < M; ++i) h.p[i] = h.pdp[i];
+          h.sel_hx ^= 1;  // e, hx <- trial values
+          h.p_e2 = h.pdp_e2;
+          h.updp = 1;
+          ++h.k;
+          h.phase = D_ITER_TOP;
           break;
         }
-        phase = D_REJECT;
+        h.phase = D_REJECT;
         break;
       }
 
       case D_REJECT: {  // lm_core.c:797-806
-        mu *= nu;
-        const int nu2 = (int)((unsigned)nu << 1);
-        if (nu2 <= nu) {
-          stop = 5;
-          phase = D_FINISH;
+        h.mu *= h.nu;
+        const int nu2 = (int)((unsigned)h.nu << 1);
+        if (nu2 <= h.nu) {
+          h.stop = 5;
+          h.phase = D_FINISH;
           break;
         }
-        nu = nu2;
-        for (int i = 0; i < M; ++i) jtj[i * M + i] = diag[i];
-        ++k;
-        phase = D_ITER_TOP;
+        h.nu = nu2;
+        for (int i = 0; i < M; ++i) h.jtj[i * M + i] = h.diag[i];
+        ++h.k;
+        h.phase = D_ITER_TOP;
         break;
       }
 
       case D_FINISH: {  // lm_core.c:809-841
-        if (k >= itmax) stop = 3;
-        for (int i = 0; i < M; ++i) jtj[i * M + i] = diag[i];
-        info[0] = init_e2;
-        info[1] = p_e2;
-        info[2] = jte_inf;
-        info[3] = dp_l2;
+        if (h.k >= c.itmax) h.stop = 3;
+        for (int i = 0; i < M; ++i) h.jtj[i * M + i] = h.diag[i];
+        c.info[0] = h.init_e2;
+        c.info[1] = h.p_e2;
+        c.info[2] = h.jte_inf;
+        c.info[3] = h.dp_l2;
         double t = -DBL_MAX;
         for (int i = 0; i < M; ++i)
-          if (t < jtj[i * M + i]) t = jtj[i * M + i];
-        info[4] = mu / t;
-        info[5] = (double)k;
-        info[6] = (double)stop;
-        info[7] = (double)nfev;
-        info[8] = (double)njap;
-        info[9] = (double)nlss;
-        if (want_covar) lu_covar<M>(jtj, covar, p_e2, n);
-        ret = (stop != 4 && stop != 7) ? k : kLmError;
-        clear_req();
-        phase = D_DONE;
+          if (t < h.jtj[i * M + i]) t = h.jtj[i * M + i];
+        c.info[4] = h.mu / t;
+        c.info[5] = (double)h.k;
+        c.info[6] = (double)h.stop;
+        c.info[7] = (double)h.nfev;
+        c.info[8] = (double)h.njap;
+        c.info[9] = (double)h.nlss;
+        if (c.want_covar) lu_covar<M>(h.jtj, c.covar, h.p_e2, c.n);
+        c.ret = (h.stop != 4 && h.stop != 7) ? h.k : kLmError;
+        clear_req(h);
+        h.phase = D_DONE;
         return;
       }
 
       default:
-        req.kind = RQ_DONE;
+        h.req.kind = RQ_DONE;
         return;
       }
     }
@@ -495,527 +534,537 @@ struct BcMachine {
     B_LS_ISSUE, B_LS_EVAL, B_PG_BEGIN, B_PG_ISSUE, B_PG_EVAL, B_PG_NORM, B_PG_JUDGE, B_COMMIT,
     B_END_ITER, B_FINISH, B_DONE
   };
-  FitOptions o;
-  int itmax, n, want_covar;
-  int has_lb, has_ub, has_dscl;
-  double lb[M], ub[M], dscl[M];
-  int phase, k, stop, nu, nfev, njev, nlss, gprev, infeasible_mask, bad_input;
-  double p[M], mu, p_e2, init_e2, jte_inf, p_l2, dp_l2, pdp_e2, keep_max;
-  double jtj[M * M], jte[M], diag[M], dp[M], pdp[M], p_start[M];
-  double t, t0, gdp;
-  // line-search locals (lmbc_core.c:218-225)
-  double ls_f0, ls_lambda, ls_plmbda, ls_pfpls, ls_tlmbda, ls_rmnlmb, ls_slp;
-  int ls_first, ls_left;
-  double info[kInfoSz], covar[M * M];
-  int ret;
-  Request<M> req;
+  struct Cold {  // configuration + results (see DifMachine for the Hot/Cold rationale)
+    FitOptions o;
+    int itmax, n, want_covar;
+    int has_lb, has_ub, has_dscl;
+    double lb[M], ub[M], dscl[M];
+    int infeasible_mask, bad_input;
+    double p_start[M];
+    double info[kInfoSz], covar[M * M];
+    int ret;
+  };
+  struct Hot {
+    int phase, k, stop, nu, nfev, njev, nlss, gprev;
+    double p[M], mu, p_e2, init_e2, jte_inf, p_l2, dp_l2, pdp_e2, keep_max;
+    double jtj[M * M], jte[M], diag[M], dp[M], pdp[M];
+    double t, t0, gdp;
+    // line-search locals (lmbc_core.c:218-225)
+    double ls_f0, ls_lambda, ls_plmbda, ls_pfpls, ls_tlmbda, ls_rmnlmb, ls_slp;
+    int ls_first, ls_left;
+    Request<M> req;
+  };
+  Cold c;
+  Hot h;
 
   LM_HD static double median3(double a, double b, double c) {  // lmbc_core.c:59-61
     return (a >= b) ? ((c >= a) ? a : ((c <= b) ? b : c)) : ((c >= b) ? b : ((c <= a) ? a : c));
   }
-  LM_HD void project(double *v) const {  // lmbc_core.c:68-88
-    if (!has_lb && !has_ub) return;
+  static LM_HD void project(const Cold &c, double *v) {  // lmbc_core.c:68-88
+    if (!c.has_lb && !c.has_ub) return;
     for (int i = M; i-- > 0;) {
-      if (has_lb && has_ub)
-        v[i] = median3(lb[i], v[i], ub[i]);
-      else if (has_ub) {
-        if (v[i] > ub[i]) v[i] = ub[i];
+      if (c.has_lb && c.has_ub)
+        v[i] = median3(c.lb[i], v[i], c.ub[i]);
+      else if (c.has_ub) {
+        if (v[i] > c.ub[i]) v[i] = c.ub[i];
       } else {
-        if (v[i] < lb[i]) v[i] = lb[i];
+        if (v[i] < c.lb[i]) v[i] = c.lb[i];
       }
     }
   }
-  LM_HD void clear_req() {
-    req.kind = RQ_DONE;
-    req.central = 0;
-    req.sel_hx = req.sel_j = 0;
-    req.dp_l2 = 0.0;
-    req.scal = 1.0;
-    for (int i = 0; i < M; ++i) req.p[i] = req.d[i] = req.q[i] = req.dp[i] = 0.0;
+  static LM_HD void clear_req(Hot &h) {
+    h.req.kind = RQ_DONE;
+    h.req.central = 0;
+    h.req.sel_hx = h.req.sel_j = 0;
+    h.req.dp_l2 = 0.0;
+    h.req.scal = 1.0;
+    for (int i = 0; i < M; ++i) h.req.p[i] = h.req.d[i] = h.req.q[i] = h.req.dp[i] = 0.0;
   }
   // ask for ||x - f(v)||^2 where v lives in the (possibly scaled) search space
-  LM_HD void request_eval(const double *v, int kind = RQ_EVAL) {
-    clear_req();
-    req.kind = kind;
-    for (int i = 0; i < M; ++i) req.p[i] = has_dscl ? v[i] * dscl[i] : v[i];
-    ++nfev;
+  static LM_HD void request_eval(const Cold &c, Hot &h, const double *v, int kind = RQ_EVAL) {
+    clear_req(h);
+    h.req.kind = kind;
+    for (int i = 0; i < M; ++i) h.req.p[i] = c.has_dscl ? v[i] * c.dscl[i] : v[i];
+    ++h.nfev;
   }
 
   LM_HD void start(const double *p0, int n_, const double *lb_, const double *ub_, const double *dscl_,
                    int itmax_, const double *opts, int want_covar_) {
-    o = make_options(opts);
+    c.o = make_options(opts);
     if (opts) {  // bc_dif reads delta as |opts[4]| and the sign as the FD flavour: lmbc_core.c:1105,1115
-      o.forward = (opts[4] >= 0.0);
-      o.delta = lm_abs(opts[4]);
+      c.o.forward = (opts[4] >= 0.0);
+      c.o.delta = lm_abs(opts[4]);
     }
-    itmax = itmax_;
-    n = n_;
-    want_covar = want_covar_;
-    has_lb = lb_ != nullptr;
-    has_ub = ub_ != nullptr;
-    has_dscl = dscl_ != nullptr;
-    k = 0;
-    stop = 0;
-    nu = 2;
-    nfev = njev = nlss = 0;
-    gprev = 0;
-    infeasible_mask = 0;
-    bad_input = 0;
-    mu = jte_inf = p_l2 = t = t0 = gdp = 0.0;
-    p_e2 = init_e2 = pdp_e2 = keep_max = 0.0;
-    dp_l2 = DBL_MAX;
-    ls_f0 = ls_lambda = ls_plmbda = ls_pfpls = ls_tlmbda = ls_rmnlmb = ls_slp = 0.0;
-    ls_first = 1;
-    ls_left = 0;
-    ret = kLmError;
+    c.itmax = itmax_;
+    c.n = n_;
+    c.want_covar = want_covar_;
+    c.has_lb = lb_ != nullptr;
+    c.has_ub = ub_ != nullptr;
+    c.has_dscl = dscl_ != nullptr;
+    h.k = 0;
+    h.stop = 0;
+    h.nu = 2;
+    h.nfev = h.njev = h.nlss = 0;
+    h.gprev = 0;
+    c.infeasible_mask = 0;
+    c.bad_input = 0;
+    h.mu = h.jte_inf = h.p_l2 = h.t = h.t0 = h.gdp = 0.0;
+    h.p_e2 = h.init_e2 = h.pdp_e2 = h.keep_max = 0.0;
+    h.dp_l2 = DBL_MAX;
+    h.ls_f0 = h.ls_lambda = h.ls_plmbda = h.ls_pfpls = h.ls_tlmbda = h.ls_rmnlmb = h.ls_slp = 0.0;
+    h.ls_first = 1;
+    h.ls_left = 0;
+    c.ret = kLmError;
     for (int i = 0; i < M; ++i) {
-      p[i] = p0[i];
-      lb[i] = has_lb ? lb_[i] : -DBL_MAX;
-      ub[i] = has_ub ? ub_[i] : DBL_MAX;
-      dscl[i] = has_dscl ? dscl_[i] : 1.0;
-      jte[i] = diag[i] = dp[i] = pdp[i] = 0.0;
+      h.p[i] = p0[i];
+      c.lb[i] = c.has_lb ? lb_[i] : -DBL_MAX;
+      c.ub[i] = c.has_ub ? ub_[i] : DBL_MAX;
+      c.dscl[i] = c.has_dscl ? dscl_[i] : 1.0;
+      h.jte[i] = h.diag[i] = h.dp[i] = h.pdp[i] = 0.0;
     }
-    for (int i = 0; i < M * M; ++i) jtj[i] = covar[i] = 0.0;
-    for (int i = 0; i < kInfoSz; ++i) info[i] = 0.0;
-    clear_req();
-    phase = B_DONE;
-    if (n < M) {  // lmbc_core.c:440-443
-      bad_input = 1;
+    for (int i = 0; i < M * M; ++i) h.jtj[i] = c.covar[i] = 0.0;
+    for (int i = 0; i < kInfoSz; ++i) c.info[i] = 0.0;
+    clear_req(h);
+    h.phase = B_DONE;
+    if (c.n < M) {  // lmbc_core.c:440-443
+      c.bad_input = 1;
       return;
     }
-    if (has_lb && has_ub)  // lmbc_core.c:451-454 (box_check, misc_core.c:661-671)
+    if (c.has_lb && c.has_ub)  // lmbc_core.c:451-454 (box_check, misc_core.c:661-671)
       for (int i = 0; i < M; ++i)
-        if (lb[i] > ub[i]) {
-          bad_input = 2;
+        if (c.lb[i] > c.ub[i]) {
+          c.bad_input = 2;
           return;
         }
-    if (has_dscl)  // lmbc_core.c:456-461
+    if (c.has_dscl)  // lmbc_core.c:456-461
       for (int i = M; i-- > 0;)
-        if (dscl[i] <= 0.0) {
-          bad_input = 3;
+        if (c.dscl[i] <= 0.0) {
+          c.bad_input = 3;
           return;
         }
-    for (int i = 0; i < M; ++i) p_start[i] = p[i];
-    project(p);  // lmbc_core.c:514-520; the stderr warning is printed by the host shim from the mask
+    for (int i = 0; i < M; ++i) c.p_start[i] = h.p[i];
+    project(c, h.p);  // lmbc_core.c:514-520; the stderr warning is printed by the host shim from the mask
     for (int i = 0; i < M; ++i)
-      if (p_start[i] != p[i]) infeasible_mask |= (1 << i);
-    clear_req();
-    req.kind = RQ_EVAL;  // the first evaluation is at the unscaled projected start, lmbc_core.c:523
-    for (int i = 0; i < M; ++i) req.p[i] = p[i];
-    phase = B_INIT_EVAL;
+      if (c.p_start[i] != h.p[i]) c.infeasible_mask |= (1 << i);
+    clear_req(h);
+    h.req.kind = RQ_EVAL;  // the first evaluation is at the unscaled projected start, lmbc_core.c:523
+    for (int i = 0; i < M; ++i) h.req.p[i] = h.p[i];
+    h.phase = B_INIT_EVAL;
   }
 
-  LM_HD void accept_trial() {  // p <- pdp, ||e||^2 <- trial value
-    for (int i = 0; i < M; ++i) p[i] = pdp[i];
-    p_e2 = pdp_e2;
+  static LM_HD void accept_trial(Hot &h) {  // p <- pdp, ||e||^2 <- trial value
+    for (int i = 0; i < M; ++i) h.p[i] = h.pdp[i];
+    h.p_e2 = h.pdp_e2;
   }
 
-  LM_HD void step(const double *s, double maxabs) {
+  LM_HD void step(const double *s, double maxabs) { run(c, h, s, maxabs); }
+
+  static LM_HD void run(Cold &c, Hot &h, const double *s, double maxabs) {
     constexpr double alpha = 1e-4, beta = 0.9, gamma = 0.99995, rho = 1e-8, tming = 1e-18, tini = 1.0;
     for (;;) {
-      switch (phase) {
+      switch (h.phase) {
       case B_INIT_EVAL:  // lmbc_core.c:523-540
-        nfev = 1;
-        p_e2 = s[0];
-        init_e2 = p_e2;
-        if (!lm_finite(p_e2)) stop = 7;
-        if (has_dscl)
+        h.nfev = 1;
+        h.p_e2 = s[0];
+        h.init_e2 = h.p_e2;
+        if (!lm_finite(h.p_e2)) h.stop = 7;
+        if (c.has_dscl)
           for (int i = M; i-- > 0;) {
-            p[i] /= dscl[i];
-            if (has_ub && ub[i] != DBL_MAX) ub[i] = ub[i] / dscl[i];
-            if (has_lb && lb[i] != -DBL_MAX) lb[i] = lb[i] / dscl[i];
+            h.p[i] /= c.dscl[i];
+            if (c.has_ub && c.ub[i] != DBL_MAX) c.ub[i] = c.ub[i] / c.dscl[i];
+            if (c.has_lb && c.lb[i] != -DBL_MAX) c.lb[i] = c.lb[i] / c.dscl[i];
           }
-        phase = B_ITER_TOP;
+        h.phase = B_ITER_TOP;
         break;
 
       case B_ITER_TOP: {
-        if (!(k < itmax && !stop)) {
-          phase = B_FINISH;
+        if (!(h.k < c.itmax && !h.stop)) {
+          h.phase = B_FINISH;
           break;
         }
-        if (p_e2 <= o.eps3) {
-          stop = 6;
-          phase = B_FINISH;
+        if (h.p_e2 <= c.o.eps3) {
+          h.stop = 6;
+          h.phase = B_FINISH;
           break;
         }
-        clear_req();  // FD Jacobian at the unscaled point, lmbc_core.c:555-561 + :1043-1054
-        req.kind = RQ_JAC;
-        req.central = !o.forward;
-        for (int i = 0; i < M; ++i) req.p[i] = has_dscl ? p[i] * dscl[i] : p[i];
-        fd_steps<M>(req.p, o.delta, req.d);
-        ++njev;
-        phase = B_AFTER_JAC;
+        clear_req(h);  // FD Jacobian at the unscaled point, lmbc_core.c:555-561 + :1043-1054
+        h.req.kind = RQ_JAC;
+        h.req.central = !c.o.forward;
+        for (int i = 0; i < M; ++i) h.req.p[i] = c.has_dscl ? h.p[i] * c.dscl[i] : h.p[i];
+        fd_steps<M>(h.req.p, c.o.delta, h.req.d);
+        ++h.njev;
+        h.phase = B_AFTER_JAC;
         return;
       }
 
       case B_AFTER_JAC: {
-        unpack_lower<M>(s, jtj);
-        for (int i = 0; i < M; ++i) jte[i] = s[SumLayout<M>::NL + i];
-        if (has_dscl) {  // J <- J*D (lmbc_core.c:562-569) folded into the reduced products
+        unpack_lower<M>(s, h.jtj);
+        for (int i = 0; i < M; ++i) h.jte[i] = s[SumLayout<M>::NL + i];
+        if (c.has_dscl) {  // J <- J*D (lmbc_core.c:562-569) folded into the reduced products
           for (int i = 0; i < M; ++i) {
-            jte[i] *= dscl[i];
-            for (int j = 0; j < M; ++j) jtj[i * M + j] *= dscl[i] * dscl[j];
+            h.jte[i] *= c.dscl[i];
+            for (int j = 0; j < M; ++j) h.jtj[i * M + j] *= c.dscl[i] * c.dscl[j];
           }
         }
         int nactive = 0, satisfied = 0;  // lmbc_core.c:639-646
-        p_l2 = jte_inf = 0.0;
+        h.p_l2 = h.jte_inf = 0.0;
         for (int i = 0; i < M; ++i) {
-          if (has_ub && p[i] == ub[i]) {
+          if (c.has_ub && h.p[i] == c.ub[i]) {
             ++nactive;
-            if (jte[i] > 0.0) ++satisfied;
-          } else if (has_lb && p[i] == lb[i]) {
+            if (h.jte[i] > 0.0) ++satisfied;
+          } else if (c.has_lb && h.p[i] == c.lb[i]) {
             ++nactive;
-            if (jte[i] < 0.0) ++satisfied;
+            if (h.jte[i] < 0.0) ++satisfied;
           } else {
-            const double a = lm_abs(jte[i]);
-            if (jte_inf < a) jte_inf = a;
+            const double a = lm_abs(h.jte[i]);
+            if (h.jte_inf < a) h.jte_inf = a;
           }
-          diag[i] = jtj[i * M + i];
-          p_l2 += p[i] * p[i];
+          h.diag[i] = h.jtj[i * M + i];
+          h.p_l2 += h.p[i] * h.p[i];
         }
-        if (satisfied == nactive && (jte_inf <= o.eps1)) {
-          dp_l2 = 0.0;
-          stop = 1;
-          phase = B_FINISH;
+        if (satisfied == nactive && (h.jte_inf <= c.o.eps1)) {
+          h.dp_l2 = 0.0;
+          h.stop = 1;
+          h.phase = B_FINISH;
           break;
         }
-        if (k == 0) {  // lmbc_core.c:666-674
-          if (!has_lb && !has_ub) {
+        if (h.k == 0) {  // lmbc_core.c:666-674
+          if (!c.has_lb && !c.has_ub) {
             double m0 = -DBL_MAX;
             for (int i = 0; i < M; ++i)
-              if (diag[i] > m0) m0 = diag[i];
-            mu = o.tau * m0;
+              if (h.diag[i] > m0) m0 = h.diag[i];
+            h.mu = c.o.tau * m0;
           } else
-            mu = 0.5 * o.tau * p_e2;  // Kanzow's starting damping
+            h.mu = 0.5 * c.o.tau * h.p_e2;  // Kanzow's starting damping
         }
-        phase = B_SOLVE;
+        h.phase = B_SOLVE;
         break;
       }
 
       case B_SOLVE: {  // lmbc_core.c:677-734
-        for (int i = 0; i < M; ++i) jtj[i * M + i] += mu;
-        const int solved = lu_solve<M>(jtj, jte, dp);
-        ++nlss;
+        for (int i = 0; i < M; ++i) h.jtj[i * M + i] += h.mu;
+        const int solved = lu_solve<M>(h.jtj, h.jte, h.dp);
+        ++h.nlss;
         if (!solved) {  // :788-804
-          mu *= nu;
-          const int nu2 = (int)((unsigned)nu << 1);
-          if (nu2 <= nu) {
-            stop = 5;
-            phase = B_END_ITER;
+          h.mu *= h.nu;
+          const int nu2 = (int)((unsigned)h.nu << 1);
+          if (nu2 <= h.nu) {
+            h.stop = 5;
+            h.phase = B_END_ITER;
             break;
           }
-          nu = nu2;
-          for (int i = 0; i < M; ++i) jtj[i * M + i] = diag[i];
+          h.nu = nu2;
+          for (int i = 0; i < M; ++i) h.jtj[i * M + i] = h.diag[i];
           break;  // solve again
         }
-        for (int i = 0; i < M; ++i) pdp[i] = p[i] + dp[i];
-        project(pdp);
-        dp_l2 = 0.0;
+        for (int i = 0; i < M; ++i) h.pdp[i] = h.p[i] + h.dp[i];
+        project(c, h.pdp);
+        h.dp_l2 = 0.0;
         for (int i = 0; i < M; ++i) {
-          const double d = pdp[i] - p[i];
-          dp[i] = d;
-          dp_l2 += d * d;
+          const double d = h.pdp[i] - h.p[i];
+          h.dp[i] = d;
+          h.dp_l2 += d * d;
         }
-        if (dp_l2 <= o.eps2sq * p_l2) {
-          stop = 2;
-          phase = B_END_ITER;
+        if (h.dp_l2 <= c.o.eps2sq * h.p_l2) {
+          h.stop = 2;
+          h.phase = B_END_ITER;
           break;
         }
-        if (dp_l2 >= (p_l2 + o.eps2) / (kEpsilon * kEpsilon)) {
-          stop = 4;
-          phase = B_END_ITER;
+        if (h.dp_l2 >= (h.p_l2 + c.o.eps2) / (kEpsilon * kEpsilon)) {
+          h.stop = 4;
+          h.phase = B_END_ITER;
           break;
         }
-        request_eval(pdp);
-        phase = B_AFTER_LM_EVAL;
+        request_eval(c, h, h.pdp);
+        h.phase = B_AFTER_LM_EVAL;
         return;
       }
 
       case B_AFTER_LM_EVAL:  // overflow guard, lmbc_core.c:748-751
-        pdp_e2 = s[0];
-        if (!lm_finite(pdp_e2)) {
+        h.pdp_e2 = s[0];
+        if (!lm_finite(h.pdp_e2)) {
           if (!lm_finite(maxabs)) {
-            stop = 7;
-            phase = B_END_ITER;
+            h.stop = 7;
+            h.phase = B_END_ITER;
             break;
           }
-          keep_max = maxabs;
-          request_eval(pdp, RQ_SCALED);
-          --nfev;  // not a user-visible function evaluation
-          req.scal = maxabs;
-          phase = B_AFTER_LM_NORM;
+          h.keep_max = maxabs;
+          request_eval(c, h, h.pdp, RQ_SCALED);
+          --h.nfev;  // not a user-visible function evaluation
+          h.req.scal = maxabs;
+          h.phase = B_AFTER_LM_NORM;
           return;
         }
-        phase = B_LM_JUDGE;
+        h.phase = B_LM_JUDGE;
         break;
 
       case B_AFTER_LM_NORM:
-        if (!lm_finite(keep_max * sqrt(s[0]))) {
-          stop = 7;
-          phase = B_END_ITER;
+        if (!lm_finite(h.keep_max * sqrt(s[0]))) {
+          h.stop = 7;
+          h.phase = B_END_ITER;
           break;
         }
-        phase = B_LM_JUDGE;
+        h.phase = B_LM_JUDGE;
         break;
 
       case B_LM_JUDGE: {
-        if (pdp_e2 <= gamma * p_e2) {  // LM step taken, lmbc_core.c:753-785
+        if (h.pdp_e2 <= gamma * h.p_e2) {  // LM step taken, lmbc_core.c:753-785
           double dL = 0.0;
-          for (int i = 0; i < M; ++i) dL += dp[i] * (mu * dp[i] + jte[i]);
+          for (int i = 0; i < M; ++i) dL += h.dp[i] * (h.mu * h.dp[i] + h.jte[i]);
           if (dL > 0.0) {
-            const double dF = p_e2 - pdp_e2;
+            const double dF = h.p_e2 - h.pdp_e2;
             double q = (2.0 * dF / dL - 1.0);
             q = 1.0 - q * q * q;
-            mu = mu * ((q >= kOneThird) ? q : kOneThird);
+            h.mu = h.mu * ((q >= kOneThird) ? q : kOneThird);
           } else {
-            const double q = 0.1 * pdp_e2;
-            mu = (mu >= q) ? q : mu;
+            const double q = 0.1 * h.pdp_e2;
+            h.mu = (h.mu >= q) ? q : h.mu;
           }
-          nu = 2;
-          accept_trial();
-          gprev = 0;
-          phase = B_END_ITER;
+          h.nu = 2;
+          accept_trial(h);
+          h.gprev = 0;
+          h.phase = B_END_ITER;
           break;
         }
-        gdp = 0.0;  // lmbc_core.c:811-816
+        h.gdp = 0.0;  // lmbc_core.c:811-816
         for (int i = 0; i < M; ++i) {
-          jte[i] = -jte[i];
-          gdp += jte[i] * dp[i];
+          h.jte[i] = -h.jte[i];
+          h.gdp += h.jte[i] * h.dp[i];
         }
-        if (!(gdp <= -rho * pow(dp_l2, kLsPow / 2.0))) {
-          phase = B_PG_BEGIN;
+        if (!(h.gdp <= -rho * pow(h.dp_l2, kLsPow / 2.0))) {
+          h.phase = B_PG_BEGIN;
           break;
         }
         // ---- line-search prologue, lmbc_core.c:227-249 (x = p, f = p_e2, g = jte, step = dp)
         const double steptl = 1e3 * sqrt(DBL_EPSILON);
-        double pn = sqrt(p_l2);
+        double pn = sqrt(h.p_l2);
         const double stepmx = 1e3 * ((pn >= 1.0) ? pn : 1.0);
-        ls_f0 = p_e2 * 0.5;
+        h.ls_f0 = h.p_e2 * 0.5;
         double acc = 0.0;
-        for (int i = M; i-- > 0;) acc += dp[i] * dp[i];
+        for (int i = M; i-- > 0;) acc += h.dp[i] * h.dp[i];
         double sln = sqrt(acc);
         if (sln > stepmx) {
           const double scl = stepmx / sln;
-          for (int i = M; i-- > 0;) dp[i] *= scl;
+          for (int i = M; i-- > 0;) h.dp[i] *= scl;
           sln = stepmx;
         }
         double rln = 0.0;
-        ls_slp = 0.0;
+        h.ls_slp = 0.0;
         for (int i = M; i-- > 0;) {
-          ls_slp += jte[i] * dp[i];
-          const double den = (lm_abs(p[i]) >= 1.0) ? lm_abs(p[i]) : 1.0;
-          const double rel = lm_abs(dp[i]) / den;
+          h.ls_slp += h.jte[i] * h.dp[i];
+          const double den = (lm_abs(h.p[i]) >= 1.0) ? lm_abs(h.p[i]) : 1.0;
+          const double rel = lm_abs(h.dp[i]) / den;
           if (rln < rel) rln = rel;
         }
-        ls_rmnlmb = steptl / rln;
-        ls_lambda = 1.0;
-        ls_first = 1;
-        ls_plmbda = ls_pfpls = ls_tlmbda = 0.0;
-        ls_left = kLsItMax;
-        phase = B_LS_ISSUE;
+        h.ls_rmnlmb = steptl / rln;
+        h.ls_lambda = 1.0;
+        h.ls_first = 1;
+        h.ls_plmbda = h.ls_pfpls = h.ls_tlmbda = 0.0;
+        h.ls_left = kLsItMax;
+        h.phase = B_LS_ISSUE;
         break;
       }
 
       case B_LS_ISSUE: {  // lmbc_core.c:253-266
-        if (ls_left-- <= 0) {  // iteration limit: failure -> projected gradient
-          phase = B_PG_BEGIN;
+        if (h.ls_left-- <= 0) {  // iteration limit: failure -> projected gradient
+          h.phase = B_PG_BEGIN;
           break;
         }
-        for (int i = M; i-- > 0;) pdp[i] = p[i] + ls_lambda * dp[i];
-        project(pdp);
-        clear_req();
-        req.kind = RQ_EVAL;
-        if (!has_dscl) {
-          for (int i = 0; i < M; ++i) req.p[i] = pdp[i];
+        for (int i = M; i-- > 0;) h.pdp[i] = h.p[i] + h.ls_lambda * h.dp[i];
+        project(c, h.pdp);
+        clear_req(h);
+        h.req.kind = RQ_EVAL;
+        if (!c.has_dscl) {
+          for (int i = 0; i < M; ++i) h.req.p[i] = h.pdp[i];
         } else {  // the reference multiplies and divides xpls in place, lmbc_core.c:263-265
           for (int i = M; i-- > 0;) {
-            pdp[i] *= dscl[i];
-            req.p[i] = pdp[i];
-            pdp[i] /= dscl[i];
+            h.pdp[i] *= c.dscl[i];
+            h.req.p[i] = h.pdp[i];
+            h.pdp[i] /= c.dscl[i];
           }
         }
-        ++nfev;
-        phase = B_LS_EVAL;
+        ++h.nfev;
+        h.phase = B_LS_EVAL;
         return;
       }
 
       case B_LS_EVAL: {  // lmbc_core.c:269-332
         const double fpls = 0.5 * s[0];
-        pdp_e2 = s[0];
-        if (fpls <= ls_f0 + ls_slp * alpha * ls_lambda) {  // satisfactory point
-          if (!lm_finite(pdp_e2)) {  // lmbc_core.c:828
-            phase = B_PG_BEGIN;
+        h.pdp_e2 = s[0];
+        if (fpls <= h.ls_f0 + h.ls_slp * alpha * h.ls_lambda) {  // satisfactory point
+          if (!lm_finite(h.pdp_e2)) {  // lmbc_core.c:828
+            h.phase = B_PG_BEGIN;
             break;
           }
-          gprev = 0;
-          phase = B_COMMIT;
+          h.gprev = 0;
+          h.phase = B_COMMIT;
           break;
         }
-        if (ls_lambda < ls_rmnlmb) {
-          phase = B_PG_BEGIN;
+        if (h.ls_lambda < h.ls_rmnlmb) {
+          h.phase = B_PG_BEGIN;
           break;
         }
         if (!lm_finite(fpls)) {
-          ls_lambda *= 0.1;
-          ls_first = 1;
+          h.ls_lambda *= 0.1;
+          h.ls_first = 1;
         } else {
-          if (ls_first) {
-            ls_tlmbda = -ls_lambda * ls_slp / ((fpls - ls_f0 - ls_slp) * 2.0);
-            ls_first = 0;
+          if (h.ls_first) {
+            h.ls_tlmbda = -h.ls_lambda * h.ls_slp / ((fpls - h.ls_f0 - h.ls_slp) * 2.0);
+            h.ls_first = 0;
           } else {
-            const double t1 = fpls - ls_f0 - ls_lambda * ls_slp;
-            const double t2 = ls_pfpls - ls_f0 - ls_plmbda * ls_slp;
-            const double t3 = 1.0 / (ls_lambda - ls_plmbda);
-            const double a3 = 3.0 * t3 * (t1 / (ls_lambda * ls_lambda) - t2 / (ls_plmbda * ls_plmbda));
-            const double b = t3 * (t2 * ls_lambda / (ls_plmbda * ls_plmbda) - t1 * ls_plmbda / (ls_lambda * ls_lambda));
-            const double disc = b * b - a3 * ls_slp;
+            const double t1 = fpls - h.ls_f0 - h.ls_lambda * h.ls_slp;
+            const double t2 = h.ls_pfpls - h.ls_f0 - h.ls_plmbda * h.ls_slp;
+            const double t3 = 1.0 / (h.ls_lambda - h.ls_plmbda);
+            const double a3 = 3.0 * t3 * (t1 / (h.ls_lambda * h.ls_lambda) - t2 / (h.ls_plmbda * h.ls_plmbda));
+            const double b = t3 * (t2 * h.ls_lambda / (h.ls_plmbda * h.ls_plmbda) - t1 * h.ls_plmbda / (h.ls_lambda * h.ls_lambda));
+            const double disc = b * b - a3 * h.ls_slp;
             if (disc > b * b)
-              ls_tlmbda = (-b + ((a3 < 0) ? -sqrt(disc) : sqrt(disc))) / a3;
+              h.ls_tlmbda = (-b + ((a3 < 0) ? -sqrt(disc) : sqrt(disc))) / a3;
             else
-              ls_tlmbda = (-b + ((a3 < 0) ? sqrt(disc) : -sqrt(disc))) / a3;
-            if (ls_tlmbda > ls_lambda * 0.5) ls_tlmbda = ls_lambda * 0.5;
+              h.ls_tlmbda = (-b + ((a3 < 0) ? sqrt(disc) : -sqrt(disc))) / a3;
+            if (h.ls_tlmbda > h.ls_lambda * 0.5) h.ls_tlmbda = h.ls_lambda * 0.5;
           }
-          ls_plmbda = ls_lambda;
-          ls_pfpls = fpls;
-          if (ls_tlmbda < ls_lambda * 0.1)
-            ls_lambda *= 0.1;
+          h.ls_plmbda = h.ls_lambda;
+          h.ls_pfpls = fpls;
+          if (h.ls_tlmbda < h.ls_lambda * 0.1)
+            h.ls_lambda *= 0.1;
           else
-            ls_lambda = ls_tlmbda;
+            h.ls_lambda = h.ls_tlmbda;
         }
-        phase = B_LS_ISSUE;
+        h.phase = B_LS_ISSUE;
         break;
       }
 
       case B_PG_BEGIN: {  // lmbc_core.c:877-885 (jte already holds -J^T e)
         double g2 = 0.0;
-        for (int i = 0; i < M; ++i) g2 += jte[i] * jte[i];
+        for (int i = 0; i < M; ++i) g2 += h.jte[i] * h.jte[i];
         g2 = sqrt(g2);
         g2 = 100.0 / (1.0 + g2);
-        t0 = (g2 <= tini) ? g2 : tini;
-        t = gprev ? t : t0;
-        phase = B_PG_ISSUE;
+        h.t0 = (g2 <= tini) ? g2 : tini;
+        h.t = h.gprev ? h.t : h.t0;
+        h.phase = B_PG_ISSUE;
         break;
       }
 
       case B_PG_ISSUE: {  // loop head of lmbc_core.c:885
-        if (!(t > tming)) {  // search failed, :937-939
-          gprev = 0;
-          phase = B_END_ITER;
+        if (!(h.t > tming)) {  // search failed, :937-939
+          h.gprev = 0;
+          h.phase = B_END_ITER;
           break;
         }
-        for (int i = 0; i < M; ++i) pdp[i] = p[i] - t * jte[i];
-        project(pdp);
-        dp_l2 = 0.0;
+        for (int i = 0; i < M; ++i) h.pdp[i] = h.p[i] - h.t * h.jte[i];
+        project(c, h.pdp);
+        h.dp_l2 = 0.0;
         for (int i = 0; i < M; ++i) {
-          const double d = pdp[i] - p[i];
-          dp[i] = d;
-          dp_l2 += d * d;
+          const double d = h.pdp[i] - h.p[i];
+          h.dp[i] = d;
+          h.dp_l2 += d * d;
         }
-        request_eval(pdp);
-        phase = B_PG_EVAL;
+        request_eval(c, h, h.pdp);
+        h.phase = B_PG_EVAL;
         return;
       }
 
       case B_PG_EVAL:
-        pdp_e2 = s[0];
-        if (!lm_finite(pdp_e2)) {  // lmbc_core.c:915-918
+        h.pdp_e2 = s[0];
+        if (!lm_finite(h.pdp_e2)) {  // lmbc_core.c:915-918
           if (!lm_finite(maxabs)) {
-            stop = 7;
-            phase = B_FINISH;
+            h.stop = 7;
+            h.phase = B_FINISH;
             break;
           }
-          keep_max = maxabs;
-          request_eval(pdp, RQ_SCALED);
-          --nfev;
-          req.scal = maxabs;
-          phase = B_PG_NORM;
+          h.keep_max = maxabs;
+          request_eval(c, h, h.pdp, RQ_SCALED);
+          --h.nfev;
+          h.req.scal = maxabs;
+          h.phase = B_PG_NORM;
           return;
         }
-        phase = B_PG_JUDGE;
+        h.phase = B_PG_JUDGE;
         break;
 
       case B_PG_NORM:
-        if (!lm_finite(keep_max * sqrt(s[0]))) {
-          stop = 7;
-          phase = B_FINISH;  // "goto breaknested": k is not advanced
+        if (!lm_finite(h.keep_max * sqrt(s[0]))) {
+          h.stop = 7;
+          h.phase = B_FINISH;  // "goto breaknested": k is not advanced
           break;
         }
-        phase = B_PG_JUDGE;
+        h.phase = B_PG_JUDGE;
         break;
 
       case B_PG_JUDGE: {  // lmbc_core.c:923-935
-        gdp = 0.0;
-        for (int i = 0; i < M; ++i) gdp += jte[i] * dp[i];
-        if (gprev && pdp_e2 <= p_e2 + 2.0 * 0.99999 * gdp) {  // remembered t was too small
-          t = t0;
-          gprev = 0;
-          t *= beta;  // the reference's `continue` still runs the loop increment
-          phase = B_PG_ISSUE;
+        h.gdp = 0.0;
+        for (int i = 0; i < M; ++i) h.gdp += h.jte[i] * h.dp[i];
+        if (h.gprev && h.pdp_e2 <= h.p_e2 + 2.0 * 0.99999 * h.gdp) {  // remembered t was too small
+          h.t = h.t0;
+          h.gprev = 0;
+          h.t *= beta;  // the reference's `continue` still runs the loop increment
+          h.phase = B_PG_ISSUE;
           break;
         }
-        if (pdp_e2 <= p_e2 + 2.0 * alpha * gdp) {
-          gprev = 1;
-          phase = B_COMMIT;
+        if (h.pdp_e2 <= h.p_e2 + 2.0 * alpha * h.gdp) {
+          h.gprev = 1;
+          h.phase = B_COMMIT;
           break;
         }
-        t *= beta;
-        phase = B_PG_ISSUE;
+        h.t *= beta;
+        h.phase = B_PG_ISSUE;
         break;
       }
 
       case B_COMMIT: {  // lmbc_core.c:950-967
-        dp_l2 = 0.0;
+        h.dp_l2 = 0.0;
         for (int i = 0; i < M; ++i) {
-          const double d = pdp[i] - p[i];
-          dp_l2 += d * d;
+          const double d = h.pdp[i] - h.p[i];
+          h.dp_l2 += d * d;
         }
-        if (dp_l2 <= o.eps2sq * p_l2) {
-          stop = 2;
-          phase = B_END_ITER;
+        if (h.dp_l2 <= c.o.eps2sq * h.p_l2) {
+          h.stop = 2;
+          h.phase = B_END_ITER;
           break;
         }
-        accept_trial();
-        phase = B_END_ITER;
+        accept_trial(h);
+        h.phase = B_END_ITER;
         break;
       }
 
       case B_END_ITER:
-        ++k;
-        phase = B_ITER_TOP;
+        ++h.k;
+        h.phase = B_ITER_TOP;
         break;
 
       case B_FINISH: {  // lmbc_core.c:973-1021, :1119-1124
-        if (k >= itmax) stop = 3;
-        for (int i = 0; i < M; ++i) jtj[i * M + i] = diag[i];
-        info[0] = init_e2;
-        info[1] = p_e2;
-        info[2] = jte_inf;
-        info[3] = dp_l2;
+        if (h.k >= c.itmax) h.stop = 3;
+        for (int i = 0; i < M; ++i) h.jtj[i * M + i] = h.diag[i];
+        c.info[0] = h.init_e2;
+        c.info[1] = h.p_e2;
+        c.info[2] = h.jte_inf;
+        c.info[3] = h.dp_l2;
         double m0 = -DBL_MAX;
         for (int i = 0; i < M; ++i)
-          if (m0 < jtj[i * M + i]) m0 = jtj[i * M + i];
-        info[4] = mu / m0;
-        info[5] = (double)k;
-        info[6] = (double)stop;
-        info[7] = (double)nfev + (double)njev * (o.forward ? (M + 1) : (2 * M));
-        info[8] = (double)njev;
-        info[9] = (double)nlss;
-        if (want_covar) {
-          lu_covar<M>(jtj, covar, p_e2, n);
-          if (has_dscl)
+          if (m0 < h.jtj[i * M + i]) m0 = h.jtj[i * M + i];
+        c.info[4] = h.mu / m0;
+        c.info[5] = (double)h.k;
+        c.info[6] = (double)h.stop;
+        c.info[7] = (double)h.nfev + (double)h.njev * (c.o.forward ? (M + 1) : (2 * M));
+        c.info[8] = (double)h.njev;
+        c.info[9] = (double)h.nlss;
+        if (c.want_covar) {
+          lu_covar<M>(h.jtj, c.covar, h.p_e2, c.n);
+          if (c.has_dscl)
             for (int i = M; i-- > 0;)
-              for (int j = M; j-- > 0;) covar[i * M + j] *= (dscl[i] * dscl[j]);
+              for (int j = M; j-- > 0;) c.covar[i * M + j] *= (c.dscl[i] * c.dscl[j]);
         }
-        if (has_dscl)
-          for (int i = 0; i < M; ++i) p[i] *= dscl[i];
-        ret = (stop != 4 && stop != 7) ? k : kLmError;
-        clear_req();
-        phase = B_DONE;
+        if (c.has_dscl)
+          for (int i = 0; i < M; ++i) h.p[i] *= c.dscl[i];
+        c.ret = (h.stop != 4 && h.stop != 7) ? h.k : kLmError;
+        clear_req(h);
+        h.phase = B_DONE;
         return;
       }
 
       default:
-        req.kind = RQ_DONE;
+        h.req.kind = RQ_DONE;
         return;
       }
     }

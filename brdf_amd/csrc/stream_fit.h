@@ -13,8 +13,8 @@ namespace brdf {
 
 constexpr int kStreamThreads = 512;
 constexpr int kStreamMaxBlocks = 512;  // width of the partial-sum rows (and of the folding reduction)
-constexpr int kStreamGridCap = 256;    // workgroups actually launched: one per CU (the pass kernel is
-                                       // register-heavy: 2 waves/SIMD, i.e. one 512-thread workgroup per CU)
+constexpr int kStreamGridCap = 256;    // workgroups actually launched: one 512-thread workgroup per CU
+constexpr int kStreamWavesPerSimd = 2; // 8 waves per CU: the register allocator may use up to 256 VGPRs (no spills)
 
 union MachineUnion {
   DifMachine<kM> dif;
@@ -34,19 +34,20 @@ struct Mailbox {
   double info[kInfoSz];
   double covar[kM * kM];
   int progress;  // last pass index that started (run-ahead throttle)
-  int pad;
+  int domain_bad;
   long long stamps[8];  // diagnostic builds only (-DBRDF_STAMPS): cycles per kernel section, summed over passes
 };
 
 struct StreamCtx {
   const double *c0, *c1, *c2, *x;
+  double *prep[2]; // per-sample invariants written by pass 0 (FAST path): q1[n], q2[n]
   double *hx[2];   // f(p) at the current / trial point          (dif only)
   double *jac[2];  // Jacobian, SoA: plane k at jac[b] + k*n     (dif only)
   double *partials;  // [2][kSlots][kStreamMaxBlocks]
   Mailbox *mbox;     // device-visible address of the pinned mailbox
   int n, nb, method, model;
   int done;  // sticky: set by the finishing pass, read by every later pass
-  int pad0;
+  int domain_bad;  // FAST path only: a cosine <= 0 was met (log undefined): the host re-runs on the exact path
   long long t_first;
   long long n_jac, n_eval;
   long long stamps[8];

@@ -14,6 +14,7 @@
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <type_traits>
 
@@ -38,27 +39,28 @@ __device__ __forceinline__ MachineOf<METHOD> *machine_slot(StreamCtx *ctx, int w
 template <int METHOD>
 __device__ void publish_result(StreamCtx *ctx, const MachineOf<METHOD> &sm, int pass) {
   Mailbox *mb = ctx->mbox;
-  mb->ret = sm.ret;
+  mb->ret = sm.c.ret;
   mb->passes = pass;
   if constexpr (METHOD == 1)
-    mb->infeasible_mask = sm.infeasible_mask;
+    mb->infeasible_mask = sm.c.infeasible_mask;
   else
     mb->infeasible_mask = 0;
   mb->t_first = ctx->t_first;
   mb->t_last = (long long)wall_clock64();
   mb->n_jac = ctx->n_jac;
   mb->n_eval = ctx->n_eval;
+  mb->domain_bad = ctx->domain_bad;
   for (int k = 0; k < 8; ++k) mb->stamps[k] = ctx->stamps[k];
-  for (int i = 0; i < kM; ++i) mb->p[i] = sm.p[i];
-  for (int i = 0; i < kInfoSz; ++i) mb->info[i] = sm.info[i];
-  for (int i = 0; i < kM * kM; ++i) mb->covar[i] = sm.covar[i];
+  for (int i = 0; i < kM; ++i) mb->p[i] = sm.h.p[i];
+  for (int i = 0; i < kInfoSz; ++i) mb->info[i] = sm.c.info[i];
+  for (int i = 0; i < kM * kM; ++i) mb->covar[i] = sm.c.covar[i];
   ctx->done = 1;
   __threadfence_system();
   __hip_atomic_store(&mb->done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-template <int MODEL, int METHOD>
-__global__ __launch_bounds__(kStreamThreads) void stream_pass(StreamCtx *ctx, int pass) {
+template <int MODEL, int METHOD, bool FAST>
+__global__ __launch_bounds__(kStreamThreads, kStreamWavesPerSimd) void stream_pass(StreamCtx *ctx, int pass) {
   using Machine = MachineOf<METHOD>;
   using Mdl = BrdfModel<MODEL>;
   __shared__ Machine sm;
@@ -66,7 +68,6 @@ __global__ __launch_bounds__(kStreamThreads) void stream_pass(StreamCtx *ctx, in
   __shared__ double red[reduce_buf_doubles<kStreamThreads>()];
   __shared__ double sums[kSlots];
 
-  if (ctx->done) return;  // the fit finished in an earlier launch: queued run-ahead launches fall through
   const int tid = threadIdx.x;
   const int par = pass & 1;
 #ifdef BRDF_STAMPS
@@ -77,22 +78,37 @@ __global__ __launch_bounds__(kStreamThreads) void stream_pass(StreamCtx *ctx, in
 #endif
   STAMP();
 
-  {  // machine state -> LDS
-    const unsigned *src = reinterpret_cast<const unsigned *>(machine_slot<METHOD>(ctx, par));
+  // Everything this launch needs from the previous one is requested up front, in one burst, so that a
+  // single global-memory round trip is paid: the sticky `done` word, the machine state and this thread's
+  // column of the previous launch's per-workgroup partial rows (written by other CUs: they miss in L2).
+  static_assert(sizeof(Machine) % 4 == 0 && sizeof(Machine) / 4 <= 2 * kStreamThreads, "machine copy layout");
+  const int done = ctx->done;
+  const unsigned *msrc = reinterpret_cast<const unsigned *>(machine_slot<METHOD>(ctx, par));
+  constexpr int kWords = (int)(sizeof(Machine) / 4);
+  const unsigned w0 = (tid < kWords) ? msrc[tid] : 0u;
+  const unsigned w1 = (tid + kStreamThreads < kWords) ? msrc[tid + kStreamThreads] : 0u;
+  double pv[kSlots];
+  {
+    const double *part = ctx->partials + (size_t)par * kSlots * kStreamMaxBlocks;
+    const bool have = pass > 0 && tid < ctx->nb;
+#pragma unroll
+    for (int k = 0; k < kSlots; ++k) pv[k] = have ? part[k * kStreamMaxBlocks + tid] : 0.0;
+  }
+  if (done) return;  // the fit finished in an earlier launch: queued run-ahead launches fall through
+  {
     unsigned *dst = reinterpret_cast<unsigned *>(&sm);
-    for (int w = tid; w < (int)(sizeof(Machine) / 4); w += kStreamThreads) dst[w] = src[w];
+    if (tid < kWords) dst[tid] = w0;
+    if (tid + kStreamThreads < kWords) dst[tid + kStreamThreads] = w1;
   }
   __syncthreads();
   STAMP();
 
   if (pass > 0) {  // fold the previous launch's per-workgroup partials and advance the LM state machine
-    const double *part = ctx->partials + (size_t)par * kSlots * kStreamMaxBlocks;
-    const int nb = ctx->nb;
-    switch (sm.req.kind) {
-    case RQ_JAC: fold_rows<SumLayout<kM>::JAC, kStreamThreads>(part, kStreamMaxBlocks, nb, red, sums); break;
-    case RQ_DIF_JAC: fold_rows<SumLayout<kM>::DIF_JAC, kStreamThreads>(part, kStreamMaxBlocks, nb, red, sums); break;
-    case RQ_DIF_TRIAL: fold_rows<SumLayout<kM>::DIF_TRIAL, kStreamThreads>(part, kStreamMaxBlocks, nb, red, sums); break;
-    default: fold_rows<1, kStreamThreads>(part, kStreamMaxBlocks, nb, red, sums); break;
+    switch (sm.h.req.kind) {
+    case RQ_JAC: block_reduce<SumLayout<kM>::JAC, kStreamThreads>(pv, pv[kSums], red, sums); break;
+    case RQ_DIF_JAC: block_reduce<SumLayout<kM>::DIF_JAC, kStreamThreads>(pv, pv[kSums], red, sums); break;
+    case RQ_DIF_TRIAL: block_reduce<SumLayout<kM>::DIF_TRIAL, kStreamThreads>(pv, pv[kSums], red, sums); break;
+    default: block_reduce<1, kStreamThreads>(pv, pv[kSums], red, sums); break;
     }
     STAMP();
     if (tid == 0) sm.step(sums, sums[kSums]);
@@ -100,12 +116,12 @@ __global__ __launch_bounds__(kStreamThreads) void stream_pass(StreamCtx *ctx, in
     STAMP();
   }
 
-  const int kind = sm.req.kind;
+  const int kind = sm.h.req.kind;
   if (kind == RQ_DONE) {
     if (blockIdx.x == 0 && tid == 0) publish_result<METHOD>(ctx, sm, pass);
     return;
   }
-  if (tid == 0) su.build(sm.req);
+  if (tid == 0) su.build(sm.h.req);
   STAMP();
   if (blockIdx.x == 0) {  // persist the advanced machine for the next launch
     const unsigned *src = reinterpret_cast<const unsigned *>(&sm);
@@ -143,93 +159,173 @@ __global__ __launch_bounds__(kStreamThreads) void stream_pass(StreamCtx *ctx, in
   double mx = 0.0;
   double *outp = ctx->partials + (size_t)(par ^ 1) * kSlots * kStreamMaxBlocks;
 
+  // Samples are taken U at a time per lane: all loads of a batch are issued before the first
+  // transcendental so that one memory round trip is paid per batch, not per sample.
+  // FAST: the first pass of a fit (pass 0) reads the raw cosine planes, derives the per-sample
+  // invariants (brdf_models.h: Prep) and parks them in two scratch planes; every later pass reads those.
+  double *__restrict__ q1p = ctx->prep[0];
+  double *__restrict__ q2p = ctx->prep[1];
+  const bool first = (pass == 0);
+#define SWEEP_BEGIN(U)                                                                        \
+  for (int base = begin + tid; base < end; base += (U) * kStreamThreads) {                    \
+    int idx[U];                                                                               \
+    bool ok[U];                                                                               \
+    double s0[U], sx[U];                                                                      \
+    Prep pq[U];                                                                               \
+    _Pragma("unroll") for (int k = 0; k < (U); ++k) {                                         \
+      const int i = base + k * kStreamThreads;                                                \
+      ok[k] = i < end;                                                                        \
+      idx[k] = ok[k] ? i : begin;                                                             \
+      s0[k] = c0[idx[k]];                                                                     \
+      sx[k] = x[idx[k]];                                                                      \
+    }                                                                                         \
+    if (!FAST || first) {                                                                     \
+      double r1[U], r2[U];                                                                    \
+      _Pragma("unroll") for (int k = 0; k < (U); ++k) {                                       \
+        r1[k] = Mdl::uses_c1 ? c1[idx[k]] : 0.0;                                              \
+        r2[k] = Mdl::uses_c2 ? c2[idx[k]] : 0.0;                                              \
+      }                                                                                       \
+      _Pragma("unroll") for (int k = 0; k < (U); ++k) {                                       \
+        pq[k] = Mdl::template prepare<FAST>(s0[k], r1[k], r2[k]);                             \
+        if (FAST && ok[k]) {                                                                  \
+          q1p[idx[k]] = pq[k].q1;                                                             \
+          if (Mdl::prep_planes > 1) q2p[idx[k]] = pq[k].q2;                                   \
+          if (!Mdl::domain_ok(s0[k], r1[k], r2[k])) ctx->domain_bad = 1;                      \
+        }                                                                                     \
+      }                                                                                       \
+    } else {                                                                                  \
+      _Pragma("unroll") for (int k = 0; k < (U); ++k) {                                       \
+        pq[k].q1 = q1p[idx[k]];                                                               \
+        pq[k].q2 = (Mdl::prep_planes > 1) ? q2p[idx[k]] : 0.0;                                \
+      }                                                                                       \
+    }
+#define SWEEP_END }
+
   switch (kind) {
   case RQ_EVAL:
-    for (int i = begin + tid; i < end; i += kStreamThreads) {
-      const double f = model_value<MODEL>(u, c0[i], Mdl::uses_c1 ? c1[i] : 0.0, Mdl::uses_c2 ? c2[i] : 0.0);
-      const double e = x[i] - f;
+    SWEEP_BEGIN(4)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const double f = model_value<MODEL, FAST>(u, s0[k], pq[k]);
+      const double e = ok[k] ? sx[k] - f : 0.0;
       acc[0] += e * e;
       mx = fmax(mx, fabs(e));
     }
+    SWEEP_END
     STAMP();
     block_reduce<1, kStreamThreads>(acc, mx, red, sums);
     break;
   case RQ_SCALED:
-    for (int i = begin + tid; i < end; i += kStreamThreads) {
-      const double f = model_value<MODEL>(u, c0[i], Mdl::uses_c1 ? c1[i] : 0.0, Mdl::uses_c2 ? c2[i] : 0.0);
-      const double t = (x[i] - f) / u.scal;
+    SWEEP_BEGIN(4)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const double f = model_value<MODEL, FAST>(u, s0[k], pq[k]);
+      const double t = ok[k] ? (sx[k] - f) / u.scal : 0.0;
       acc[0] += t * t;
     }
+    SWEEP_END
     STAMP();
     block_reduce<1, kStreamThreads>(acc, mx, red, sums);
     break;
   case RQ_JAC:
-    for (int i = begin + tid; i < end; i += kStreamThreads) {
+    SWEEP_BEGIN(4)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
       double f0 = 0.0, j[kM];
-      model_fd_row<MODEL>(u, c0[i], Mdl::uses_c1 ? c1[i] : 0.0, Mdl::uses_c2 ? c2[i] : 0.0, true, f0, 0.0, false, j);
-      const double e = x[i] - f0;
+      model_fd_row<MODEL, FAST>(u, s0[k], pq[k], true, f0, 0.0, false, j);
+      double e = sx[k] - f0;
+      if (!ok[k]) e = j[0] = j[1] = j[2] = 0.0;
       acc_normal_eq(j, e, acc, acc + kNL);
       acc[kNL + kM] += e * e;
     }
+    SWEEP_END
     STAMP();
     block_reduce<SumLayout<kM>::JAC, kStreamThreads>(acc, mx, red, sums);
     break;
   case RQ_DIF_INIT: {
-    double *__restrict__ hx = ctx->hx[sm.req.sel_hx];
-    for (int i = begin + tid; i < end; i += kStreamThreads) {
-      const double f = model_value<MODEL>(u, c0[i], Mdl::uses_c1 ? c1[i] : 0.0, Mdl::uses_c2 ? c2[i] : 0.0);
-      hx[i] = f;
-      const double e = x[i] - f;
+    double *__restrict__ hx = ctx->hx[sm.h.req.sel_hx];
+    SWEEP_BEGIN(4)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const double f = model_value<MODEL, FAST>(u, s0[k], pq[k]);
+      if (ok[k]) hx[idx[k]] = f;
+      const double e = ok[k] ? sx[k] - f : 0.0;
       acc[0] += e * e;
     }
+    SWEEP_END
     STAMP();
     block_reduce<1, kStreamThreads>(acc, mx, red, sums);
     break;
   }
   case RQ_DIF_JAC: {
-    const double *__restrict__ hx = ctx->hx[sm.req.sel_hx];
-    double *__restrict__ jb = ctx->jac[sm.req.sel_j];
-    for (int i = begin + tid; i < end; i += kStreamThreads) {
+    const double *__restrict__ hx = ctx->hx[sm.h.req.sel_hx];
+    double *__restrict__ jb = ctx->jac[sm.h.req.sel_j];
+    SWEEP_BEGIN(4)
+    double h[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) h[k] = hx[idx[k]];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
       double f0 = 0.0, j[kM];
-      const double h = hx[i];
-      model_fd_row<MODEL>(u, c0[i], Mdl::uses_c1 ? c1[i] : 0.0, Mdl::uses_c2 ? c2[i] : 0.0, false, f0, h, true, j);
-      jb[i] = j[0];
-      jb[(size_t)n + i] = j[1];
-      jb[2 * (size_t)n + i] = j[2];
-      acc_normal_eq(j, x[i] - h, acc, acc + kNL);
+      model_fd_row<MODEL, FAST>(u, s0[k], pq[k], false, f0, h[k], true, j);
+      double e = sx[k] - h[k];
+      if (ok[k]) {
+        jb[idx[k]] = j[0];
+        jb[(size_t)n + idx[k]] = j[1];
+        jb[2 * (size_t)n + idx[k]] = j[2];
+      } else {
+        e = j[0] = j[1] = j[2] = 0.0;
+      }
+      acc_normal_eq(j, e, acc, acc + kNL);
     }
+    SWEEP_END
     STAMP();
     block_reduce<SumLayout<kM>::DIF_JAC, kStreamThreads>(acc, mx, red, sums);
     break;
   }
   case RQ_DIF_TRIAL: {
-    const double *__restrict__ hx = ctx->hx[sm.req.sel_hx];
-    double *__restrict__ hn = ctx->hx[sm.req.sel_hx ^ 1];
-    const double *__restrict__ jo = ctx->jac[sm.req.sel_j];
-    double *__restrict__ jn = ctx->jac[sm.req.sel_j ^ 1];
-    for (int i = begin + tid; i < end; i += kStreamThreads) {
-      const double w = model_value_q<MODEL>(u, c0[i], Mdl::uses_c1 ? c1[i] : 0.0, Mdl::uses_c2 ? c2[i] : 0.0);
-      const double h = hx[i], xi = x[i];
-      const double jold[kM] = {jo[i], jo[(size_t)n + i], jo[2 * (size_t)n + i]};
+    const double *__restrict__ hx = ctx->hx[sm.h.req.sel_hx];
+    double *__restrict__ hn = ctx->hx[sm.h.req.sel_hx ^ 1];
+    const double *__restrict__ jo = ctx->jac[sm.h.req.sel_j];
+    double *__restrict__ jn = ctx->jac[sm.h.req.sel_j ^ 1];
+    SWEEP_BEGIN(4)
+    double h[4], jold[4][kM];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      h[k] = hx[idx[k]];
+      jold[k][0] = jo[idx[k]];
+      jold[k][1] = jo[(size_t)n + idx[k]];
+      jold[k][2] = jo[2 * (size_t)n + idx[k]];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const double w = model_value_q<MODEL, FAST>(u, s0[k], pq[k]);
       double j[kM];
-      broyden_row(jold, w, h, u.dp, u.dp_l2, j);
-      hn[i] = w;
-      jn[i] = j[0];
-      jn[(size_t)n + i] = j[1];
-      jn[2 * (size_t)n + i] = j[2];
-      const double en = xi - w, eo = xi - h;
+      broyden_row(jold[k], w, h[k], u.dp, u.dp_l2, j);
+      double en = sx[k] - w, eo = sx[k] - h[k];
+      if (ok[k]) {
+        hn[idx[k]] = w;
+        jn[idx[k]] = j[0];
+        jn[(size_t)n + idx[k]] = j[1];
+        jn[2 * (size_t)n + idx[k]] = j[2];
+      } else {
+        en = eo = j[0] = j[1] = j[2] = 0.0;
+      }
       acc[0] += en * en;
       acc_normal_eq(j, en, acc + 1, acc + 1 + kNL);
       acc[1 + kNL + kM + 0] += j[0] * eo;
       acc[1 + kNL + kM + 1] += j[1] * eo;
       acc[1 + kNL + kM + 2] += j[2] * eo;
     }
+    SWEEP_END
     STAMP();
     block_reduce<SumLayout<kM>::DIF_TRIAL, kStreamThreads>(acc, mx, red, sums);
     break;
   }
   default: return;
   }
+#undef SWEEP_BEGIN
+#undef SWEEP_END
 
   if (tid < kSlots) outp[tid * kStreamMaxBlocks + blockIdx.x] = sums[tid];
   STAMP();
@@ -248,7 +344,7 @@ __global__ __launch_bounds__(256) void model_eval_kernel(const double *__restric
   PassUniforms<MODEL> u;
   u.build(r);
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-    hx[i] = model_value<MODEL>(u, c0[i], Mdl::uses_c1 ? c1[i] : 0.0, Mdl::uses_c2 ? c2[i] : 0.0);
+    hx[i] = model_value<MODEL, false>(u, c0[i], Mdl::template prepare<false>(c0[i], Mdl::uses_c1 ? c1[i] : 0.0, Mdl::uses_c2 ? c2[i] : 0.0));
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -282,7 +378,7 @@ struct Workspace {
   Mailbox *h_mbox = nullptr;   // pinned + mapped
   Mailbox *d_mbox = nullptr;
   double *d_partials = nullptr;
-  double *d_dif = nullptr;  // 2*n (hx) + 6*n (two SoA Jacobians)
+  double *d_dif = nullptr;  // per-sample scratch: 2n prepared planes + (dif) 2n hx + 6n two SoA Jacobians
   size_t dif_cap = 0;
   hipStream_t last_stream = nullptr;
   bool used = false;
@@ -305,7 +401,7 @@ struct Workspace {
     if (d_dif) (void)hipFree(d_dif);
     d_dif = nullptr;
     dif_cap = 0;
-    HIP_OK(hipMalloc(&d_dif, sizeof(double) * 8 * n));
+    HIP_OK(hipMalloc(&d_dif, sizeof(double) * 10 * n));
     dif_cap = n;
     return 0;
   }
@@ -327,13 +423,16 @@ struct Workspace {
 thread_local Workspace g_ws;
 
 using PassFn = void (*)(StreamCtx *, int);
-PassFn pass_kernel(int model, int method) {
-  static const PassFn table[MODEL_COUNT][2] = {
-      {stream_pass<0, 0>, stream_pass<0, 1>},
-      {stream_pass<1, 0>, stream_pass<1, 1>},
-      {stream_pass<2, 0>, stream_pass<2, 1>},
+PassFn pass_kernel(int model, int method, bool fast) {
+  static const PassFn table[2][MODEL_COUNT][2] = {
+      {{stream_pass<0, 0, false>, stream_pass<0, 1, false>},
+       {stream_pass<1, 0, false>, stream_pass<1, 1, false>},
+       {stream_pass<2, 0, false>, stream_pass<2, 1, false>}},
+      {{stream_pass<0, 0, true>, stream_pass<0, 1, true>},
+       {stream_pass<1, 0, true>, stream_pass<1, 1, true>},
+       {stream_pass<2, 0, true>, stream_pass<2, 1, true>}},
   };
-  return table[model][method];
+  return table[fast ? 1 : 0][model][method];
 }
 
 int blocks_for(int n) {
@@ -348,29 +447,13 @@ int blocks_for(int n) {
 }  // namespace
 
 FitStats stream_fit_last_stats() { return g_ws.stats; }
+bool brdf_fast_path_enabled();
 
-int stream_fit_run(const StreamFitArgs &a) {
-  if (a.model < 0 || a.model >= MODEL_COUNT) {
-    set_error("unknown BRDF model %d (0 Phong, 1 Blinn-Phong, 2 Ward)", a.model);
-    return kLmError;
-  }
-  if (a.method != 0 && a.method != 1) {
-    set_error("unknown method %d (0 dlevmar_dif, 1 dlevmar_bc_dif)", a.method);
-    return kLmError;
-  }
-  if (!a.p || !a.d_angles || a.n <= 0) {
-    set_error("null parameter vector / sample planes, or n <= 0");
-    return kLmError;
-  }
-  (void)hipGetLastError();  // drop any stale sticky error left by unrelated runtime calls on this thread
-  int dev = 0;
-  HIP_OK(hipGetDevice(&dev));
+// one attempt on the FAST (prepared-sample) or the exact model path; *retry_exact is set when the FAST path
+// met a cosine <= 0 and the result must be discarded
+static int stream_fit_attempt(const StreamFitArgs &a, bool fast, bool *retry_exact) {
+  *retry_exact = false;
   Workspace &ws = g_ws;
-  if (ws.ensure(dev) != 0) return kLmError;
-  if (ws.used && ws.last_stream != a.stream) HIP_OK(hipStreamSynchronize(ws.last_stream));
-  ws.last_stream = a.stream;
-  ws.used = true;
-
   StreamCtx &h = *ws.h_ctx;
   // the previous call may still have run-ahead launches queued that read d_ctx; the upload below is
   // stream-ordered behind them, but the pinned staging copy must not change under an in-flight copy
@@ -386,46 +469,44 @@ int stream_fit_run(const StreamFitArgs &a) {
   h.nb = blocks_for(a.n);
   h.method = a.method;
   h.model = a.model;
-
-  if (!a.d_x) {
-    set_error("x == NULL (zero measurement vector) is not supported on the device path");
-    return kLmError;
-  }
+  if (ws.ensure_dif((size_t)a.n) != 0) return kLmError;
+  h.prep[0] = ws.d_dif;
+  h.prep[1] = ws.d_dif + (size_t)a.n;
+  h.hx[0] = ws.d_dif + 2 * (size_t)a.n;
+  h.hx[1] = ws.d_dif + 3 * (size_t)a.n;
+  h.jac[0] = ws.d_dif + 4 * (size_t)a.n;
+  h.jac[1] = ws.d_dif + 7 * (size_t)a.n;
 
   if (a.method == 0) {
-    if (ws.ensure_dif((size_t)a.n) != 0) return kLmError;
-    h.hx[0] = ws.d_dif;
-    h.hx[1] = ws.d_dif + (size_t)a.n;
-    h.jac[0] = ws.d_dif + 2 * (size_t)a.n;
-    h.jac[1] = ws.d_dif + 5 * (size_t)a.n;
     DifMachine<kM> &m = h.m[0].dif;
     m.start(a.p, a.n, a.itmax, a.opts, a.covar != nullptr);
-    if (m.req.kind == RQ_DONE) {
+    if (m.h.req.kind == RQ_DONE) {
       set_error("dlevmar_dif(): cannot solve a problem with fewer measurements [%d] than unknowns [%d]", a.n, kM);
       return kLmError;
     }
   } else {
     BcMachine<kM> &m = h.m[0].bc;
     m.start(a.p, a.n, a.lb, a.ub, a.dscl, a.itmax, a.opts, a.covar != nullptr);
-    if (m.req.kind == RQ_DONE) {
-      switch (m.bad_input) {
+    if (m.h.req.kind == RQ_DONE) {
+      switch (m.c.bad_input) {
       case 1: set_error("dlevmar_bc_dif(): cannot solve a problem with fewer measurements [%d] than unknowns [%d]", a.n, kM); break;
       case 2: set_error("dlevmar_bc_dif(): at least one lower bound exceeds the upper one"); break;
       default: set_error("dlevmar_bc_dif(): scaling constants should be positive"); break;
       }
       return kLmError;
     }
-    for (int i = 0; i < kM; ++i)  // same warning as lmbc_core.c:516-520
-      if (m.infeasible_mask & (1 << i))
-        fprintf(stderr, "Warning: component %d of starting point not feasible in dlevmar_bc_dif()! [%g projected to %g]\n",
-                i, m.p_start[i], m.p[i]);
+    if (fast || !brdf_fast_path_enabled())  // (an exact re-run must not print the warning twice)
+      for (int i = 0; i < kM; ++i)          // same warning as lmbc_core.c:516-520
+        if (m.c.infeasible_mask & (1 << i))
+          fprintf(stderr, "Warning: component %d of starting point not feasible in dlevmar_bc_dif()! [%g projected to %g]\n",
+                  i, m.c.p_start[i], m.h.p[i]);
   }
 
   Mailbox &mb = *ws.h_mbox;
   memset(&mb, 0, sizeof mb);
   HIP_OK(hipMemcpyAsync(ws.d_ctx, &h, sizeof h, hipMemcpyHostToDevice, a.stream));
 
-  const PassFn fn = pass_kernel(a.model, a.method);
+  const PassFn fn = pass_kernel(a.model, a.method, fast);
   const dim3 grid(h.nb), block(kStreamThreads);
   constexpr int kRunAhead = 6;
   const long long cap = (long long)(a.itmax > 0 ? a.itmax : 1) * 700 + 64;  // LM + <=150 LS + ~400 PG evals per iteration
@@ -455,6 +536,10 @@ int stream_fit_run(const StreamFitArgs &a) {
   }
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
   HIP_OK(hipGetLastError());
+  if (fast && mb.domain_bad) {
+    *retry_exact = true;
+    return 0;
+  }
 
   for (int i = 0; i < kM; ++i) a.p[i] = mb.p[i];
   if (a.info)
@@ -467,6 +552,49 @@ int stream_fit_run(const StreamFitArgs &a) {
   ws.stats.device_us = (double)(mb.t_last - mb.t_first) / 100.0;  // s_memrealtime ticks at 100 MHz
   for (int k = 0; k < 8; ++k) ws.stats.stamps[k] = mb.stamps[k];
   return mb.ret;
+}
+
+// BRDF_HIP_EXACT_POW=1 forces the exact model path (reference expression, pow per evaluation)
+bool brdf_fast_path_enabled() {
+  const char *e = getenv("BRDF_HIP_EXACT_POW");
+  return !(e && e[0] == '1');
+}
+
+int stream_fit_run(const StreamFitArgs &a) {
+  if (a.model < 0 || a.model >= MODEL_COUNT) {
+    set_error("unknown BRDF model %d (0 Phong, 1 Blinn-Phong, 2 Ward)", a.model);
+    return kLmError;
+  }
+  if (a.method != 0 && a.method != 1) {
+    set_error("unknown method %d (0 dlevmar_dif, 1 dlevmar_bc_dif)", a.method);
+    return kLmError;
+  }
+  if (!a.p || !a.d_angles || a.n <= 0) {
+    set_error("null parameter vector / sample planes, or n <= 0");
+    return kLmError;
+  }
+  if (!a.d_x) {
+    set_error("x == NULL (zero measurement vector) is not supported on the device path");
+    return kLmError;
+  }
+  (void)hipGetLastError();  // drop any stale sticky error left by unrelated runtime calls on this thread
+  int dev = 0;
+  HIP_OK(hipGetDevice(&dev));
+  Workspace &ws = g_ws;
+  if (ws.ensure(dev) != 0) return kLmError;
+  if (ws.used && ws.last_stream != a.stream) HIP_OK(hipStreamSynchronize(ws.last_stream));
+  ws.last_stream = a.stream;
+  ws.used = true;
+
+  double p_keep[kM];
+  for (int i = 0; i < kM; ++i) p_keep[i] = a.p[i];
+  bool retry = false;
+  int ret = stream_fit_attempt(a, brdf_fast_path_enabled(), &retry);
+  if (retry) {  // a cosine <= 0 on the cached-log path: redo with the reference's pow expression
+    for (int i = 0; i < kM; ++i) a.p[i] = p_keep[i];
+    ret = stream_fit_attempt(a, false, &retry);
+  }
+  return ret;
 }
 
 int model_eval_run(int model, const double *d_angles, int n, const double *p, double *d_hx, hipStream_t stream) {

@@ -54,7 +54,7 @@ def model_value(model: int, p, c0, c1, c2):
     if model == 2:
         a2 = p2 * p2
         t2 = (1.0 - c1 * c1) / (c1 * c1)
-        spec = (1.0 / (4.0 * PI * a2)) * np.exp(-t2 / a2) / np.sqrt(c0 * c2)
+        spec = ((1.0 / (4.0 * PI * a2)) * np.exp(-(t2 * (1.0 / a2)))) * (1.0 / np.sqrt(c0 * c2))
         return c0 * (p0 / PI + p1 * spec)
     raise ValueError(f"unknown model {model}")
 

@@ -33,16 +33,19 @@ void orc_brdf_func(double *p, double *hx, int m, int n, void *adata)
     for (i = 0; i < n; ++i)
       hx[i] = p[0] * c_ln[i] + p[1] * (pow(c_nh[i], p[2]));
     break;
-  case 2: { /* Ward (isotropic, 1992), build-defined: p = (rho_d, rho_s, alpha) */
+  case 2: { /* Ward (isotropic, 1992), build-defined: p = (rho_d, rho_s, alpha).  Written with
+             * reciprocals so the sample invariants tan^2(theta_h) and 1/sqrt(ci*co) are separable. */
     const double a2 = p[2] * p[2];
+    const double ia2 = 1.0 / a2;
     const double k = 1.0 / (4.0 * ORC_PI * a2);
     const double dterm = p[0] / ORC_PI;
     for (i = 0; i < n; ++i) {
       const double ci = c_ln[i], ch = c_nh[i], co = c_p2[i];
       const double ch2 = ch * ch;
-      const double t2 = (1.0 - ch2) / ch2;  /* tan^2(theta_h) */
-      const double g = exp(-t2 / a2);
-      const double spec = k * g / sqrt(ci * co);
+      const double t2 = (1.0 - ch2) / ch2; /* tan^2(theta_h) */
+      const double rinv = 1.0 / sqrt(ci * co);
+      const double g = exp(-(t2 * ia2));
+      const double spec = (k * g) * rinv;
       hx[i] = ci * (dterm + p[1] * spec);
     }
     break;

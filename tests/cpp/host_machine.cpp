@@ -17,8 +17,12 @@ using namespace brdf;
 
 namespace {
 
-template <int MODEL>
+template <int MODEL, bool FAST>
 struct HostPasses {
+  using Mdl = BrdfModel<MODEL>;
+  // FAST = false: raw cosines + the reference's pow (bit-exact target).  FAST = true: the prepared-sample
+  // path the GPU kernels use (cached log / tan^2 / rsqrt), here with host libm.
+  Prep prep(int i) const { return Mdl::template prepare<FAST>(c0[i], c1[i], c2[i]); }
   const double *c0, *c1, *c2, *x;
   int n, bc_rule;
   std::vector<double> e, e2, jac, hx[2], J[2];
@@ -46,7 +50,7 @@ struct HostPasses {
     switch (r.kind) {
     case RQ_EVAL:
     case RQ_SCALED: {
-      for (int i = 0; i < n; ++i) f[i] = model_value<MODEL>(u, c0[i], c1[i], c2[i]);
+      for (int i = 0; i < n; ++i) f[i] = model_value<MODEL, FAST>(u, c0[i], prep(i));
       s[0] = orc_l2_residual(e.data(), x, f.data(), n);
       for (int i = 0; i < n; ++i) mx = fmax(mx, fabs(e[i]));
       if (r.kind == RQ_SCALED) {  // lmbc_core.c:163-166, descending
@@ -62,7 +66,7 @@ struct HostPasses {
     case RQ_JAC: {
       for (int i = 0; i < n; ++i) {
         double f0 = 0.0;
-        model_fd_row<MODEL>(u, c0[i], c1[i], c2[i], true, f0, 0.0, false, &jac[3 * i]);
+        model_fd_row<MODEL, FAST>(u, c0[i], prep(i), true, f0, 0.0, false, &jac[3 * i]);
         f[i] = f0;
       }
       s[SumLayout<3>::NL + 3] = orc_l2_residual(e.data(), x, f.data(), n);
@@ -73,7 +77,7 @@ struct HostPasses {
     }
     case RQ_DIF_INIT: {
       std::vector<double> &h = hx[r.sel_hx];
-      for (int i = 0; i < n; ++i) h[i] = model_value<MODEL>(u, c0[i], c1[i], c2[i]);
+      for (int i = 0; i < n; ++i) h[i] = model_value<MODEL, FAST>(u, c0[i], prep(i));
       s[0] = orc_l2_residual(e.data(), x, h.data(), n);
       break;
     }
@@ -82,7 +86,7 @@ struct HostPasses {
       std::vector<double> &Jc = J[r.sel_j];
       for (int i = 0; i < n; ++i) {
         double f0 = 0.0;
-        model_fd_row<MODEL>(u, c0[i], c1[i], c2[i], false, f0, h[i], true, &Jc[3 * i]);
+        model_fd_row<MODEL, FAST>(u, c0[i], prep(i), false, f0, h[i], true, &Jc[3 * i]);
         e[i] = x[i] - h[i];
       }
       orc_jtj_jte(Jc.data(), e.data(), jtj, jte, n, 3, 0);
@@ -96,7 +100,7 @@ struct HostPasses {
       std::vector<double> &Jc = J[r.sel_j];
       std::vector<double> &Jn = J[r.sel_j ^ 1];
       for (int i = 0; i < n; ++i) {
-        hn[i] = model_value_q<MODEL>(u, c0[i], c1[i], c2[i]);
+        hn[i] = model_value_q<MODEL, FAST>(u, c0[i], prep(i));
         broyden_row(&Jc[3 * i], hn[i], h[i], u.dp, u.dp_l2, &Jn[3 * i]);
         e[i] = x[i] - h[i];
       }
@@ -114,40 +118,40 @@ struct HostPasses {
   }
 };
 
-template <int MODEL>
+template <int MODEL, bool FAST>
 int fit(int method, double *angles, double *x, int n, double *p, int itmax, double *opts, double *lb,
         double *ub, double *dscl, double *info, double *covar, int *passes) {
   double s[SumLayout<3>::MAX] = {0};
   double mx = 0.0;
   int np = 0;
   if (method == 0) {
-    HostPasses<MODEL> hp(angles, x, n, 0);
+    HostPasses<MODEL, FAST> hp(angles, x, n, 0);
     DifMachine<3> m;
     m.start(p, n, itmax, opts, covar != nullptr);
-    while (m.req.kind != RQ_DONE) {
-      hp.run(m.req, s, mx);
+    while (m.h.req.kind != RQ_DONE) {
+      hp.run(m.h.req, s, mx);
       ++np;
       m.step(s, mx);
     }
-    for (int i = 0; i < 3; ++i) p[i] = m.p[i];
-    if (info) for (int i = 0; i < 10; ++i) info[i] = m.info[i];
-    if (covar) for (int i = 0; i < 9; ++i) covar[i] = m.covar[i];
+    for (int i = 0; i < 3; ++i) p[i] = m.h.p[i];
+    if (info) for (int i = 0; i < 10; ++i) info[i] = m.c.info[i];
+    if (covar) for (int i = 0; i < 9; ++i) covar[i] = m.c.covar[i];
     if (passes) *passes = np;
-    return m.ret;
+    return m.c.ret;
   }
-  HostPasses<MODEL> hp(angles, x, n, 1);
+  HostPasses<MODEL, FAST> hp(angles, x, n, 1);
   BcMachine<3> m;
   m.start(p, n, lb, ub, dscl, itmax, opts, covar != nullptr);
-  while (m.req.kind != RQ_DONE) {
-    hp.run(m.req, s, mx);
+  while (m.h.req.kind != RQ_DONE) {
+    hp.run(m.h.req, s, mx);
     ++np;
     m.step(s, mx);
   }
-  for (int i = 0; i < 3; ++i) p[i] = m.p[i];
-  if (info) for (int i = 0; i < 10; ++i) info[i] = m.info[i];
-  if (covar) for (int i = 0; i < 9; ++i) covar[i] = m.covar[i];
+  for (int i = 0; i < 3; ++i) p[i] = m.h.p[i];
+  if (info) for (int i = 0; i < 10; ++i) info[i] = m.c.info[i];
+  if (covar) for (int i = 0; i < 9; ++i) covar[i] = m.c.covar[i];
   if (passes) *passes = np;
-  return m.ret;
+  return m.c.ret;
 }
 
 }  // namespace
@@ -156,9 +160,21 @@ extern "C" int hm_brdf_fit(int method, int model, double *angles, double *x, int
                            double *opts, double *lb, double *ub, double *dscl, double *info,
                            double *covar, int *passes) {
   switch (model) {
-  case 0: return fit<0>(method, angles, x, n, p, itmax, opts, lb, ub, dscl, info, covar, passes);
-  case 1: return fit<1>(method, angles, x, n, p, itmax, opts, lb, ub, dscl, info, covar, passes);
-  case 2: return fit<2>(method, angles, x, n, p, itmax, opts, lb, ub, dscl, info, covar, passes);
+  case 0: return fit<0, false>(method, angles, x, n, p, itmax, opts, lb, ub, dscl, info, covar, passes);
+  case 1: return fit<1, false>(method, angles, x, n, p, itmax, opts, lb, ub, dscl, info, covar, passes);
+  case 2: return fit<2, false>(method, angles, x, n, p, itmax, opts, lb, ub, dscl, info, covar, passes);
+  }
+  return -1;
+}
+
+// the same with the prepared-sample (FAST) model path
+extern "C" int hm_brdf_fit_fast(int method, int model, double *angles, double *x, int n, double *p, int itmax,
+                                double *opts, double *lb, double *ub, double *dscl, double *info,
+                                double *covar, int *passes) {
+  switch (model) {
+  case 0: return fit<0, true>(method, angles, x, n, p, itmax, opts, lb, ub, dscl, info, covar, passes);
+  case 1: return fit<1, true>(method, angles, x, n, p, itmax, opts, lb, ub, dscl, info, covar, passes);
+  case 2: return fit<2, true>(method, angles, x, n, p, itmax, opts, lb, ub, dscl, info, covar, passes);
   }
   return -1;
 }

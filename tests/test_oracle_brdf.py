@@ -107,3 +107,19 @@ def test_too_few_measurements_is_an_error():
     for which in ("orc", "hm"):
         for method in (0, 1):
             assert L.brdf_fit(which, method, 1, angles, x, synth.P0[1], 10, synth.OPTS, synth.LB, synth.UB)[0] == -1
+
+
+@pytest.mark.parametrize("model", [0, 1, 2])
+@pytest.mark.parametrize("method", [0, 1])
+def test_prepared_sample_path_matches_oracle_within_tolerance(method, model):
+    """the FAST model path of the GPU kernels (cached log / tan^2 / rsqrt, one exp per evaluation), run on the
+    host through the same headers: Ward is bit-identical to the exact path, Phong/Blinn-Phong differ from
+    pow() by < 1 ulp of the model value, so fitted parameters agree far inside the 1e-5 parity tolerance"""
+    n = 2000
+    angles, x, _ = synth.make_single(model, n)
+    a = L.brdf_fit("orc", method, model, angles, x, synth.P0[model], synth.ITMAX, synth.OPTS, synth.LB, synth.UB)
+    b = L.brdf_fit("hm_fast", method, model, angles, x, synth.P0[model], synth.ITMAX, synth.OPTS, synth.LB, synth.UB)
+    if model == 2:
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    else:
+        assert b[0] >= 0 and L.rel_err(b[1], a[1]) <= 1e-7 and abs(b[2][1] - a[2][1]) <= 1e-10 * a[2][1]
