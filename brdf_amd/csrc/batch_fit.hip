@@ -1,7 +1,401 @@
-// placeholder translation unit, replaced below
+// batch_fit.hip -- batched regime: S independent fits, one workgroup (or one wavefront) per fit.
+//
+// Replaces the serial pixel x colour-channel loop of CBRDFdata::CalcBRDFEquation
+// (brdfdata.cpp:1195-1220): each of its iterations packs 16 samples and calls dlevmar_bc_dif
+// (brdfdata.cpp:1077-1136).  Here the fits are independent workgroups; a fit's samples are read from
+// HBM exactly once (24-32 B per sample) into REGISTERS, its per-sample invariants (brdf_models.h: Prep)
+// are derived once, and the entire LM iteration -- model evaluation, residuals, FD Jacobian, J^T J /
+// J^T e, Broyden update, 3x3 solve, line search -- runs out of registers + ~3 KB of LDS.  A "pass" is a
+// sweep over the lane's SPT cached samples followed by a DPP/LDS workgroup reduction; the scalar LM
+// state machine (lm_machine.h) lives in LDS and is stepped by lane 0.  Fits finish after different
+// numbers of passes; the hardware workgroup scheduler backfills, which is the load balancing.
+#include <cstring>
+#include <type_traits>
+
 #include "batch_fit.h"
 #include "stream_fit.h"
+
 namespace brdf {
-int batch_fit_enqueue(const BatchFitArgs &) { set_error("batched regime not built yet"); return kLmError; }
-int synth_enqueue(int, unsigned long long, long long, int, int, const double *, double *, double *, hipStream_t) { set_error("synth not built yet"); return kLmError; }
+
+constexpr int kNeedsExact = -2;  // flag value: this fit has a cosine <= 0 and must take the exact model path
+
+struct BatchCtx {
+  const double *angles;  // [S][3][n]
+  const double *x;       // [S][n]
+  double *p;             // [S][3] in/out
+  double *info;          // [S][10] or null
+  int *ret;              // [S] or null
+  int *flags;            // [S] internal: kNeedsExact marks fits handed to the exact kernel
+  int S, n, itmax;
+  int has_opts, has_lb, has_ub;
+  double opts[5], lb[kM], ub[kM];
+};
+
+template <int METHOD>
+using BatchMachine = typename std::conditional<METHOD == 0, DifMachine<kM>, BcMachine<kM>>::type;
+
+template <int MODEL, int METHOD, bool FAST, int THREADS, int SPT>
+__global__ __launch_bounds__(THREADS) void batch_fit_kernel(BatchCtx ctx) {
+  using Machine = BatchMachine<METHOD>;
+  using Mdl = BrdfModel<MODEL>;
+  __shared__ Machine sm;
+  __shared__ PassUniforms<MODEL> su;
+  __shared__ double red[reduce_buf_doubles<THREADS>()];
+  __shared__ double sums[kSlots];
+  __shared__ int bad_domain;
+
+  const int fit = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int n = ctx.n;
+  if (!FAST && ctx.flags[fit] != kNeedsExact) return;  // exact kernel: only the fits the fast kernel declined
+
+  // ---- the fit's samples: one HBM read, then registers --------------------------------------------------
+  const double *__restrict__ c0 = ctx.angles + (size_t)fit * 3 * n;
+  const double *__restrict__ c1 = c0 + n;
+  const double *__restrict__ c2 = c0 + 2 * (size_t)n;
+  const double *__restrict__ xs = ctx.x + (size_t)fit * n;
+  double s0[SPT], sx[SPT];
+  Prep pq[SPT];
+  bool ok[SPT];
+  if (tid == 0) bad_domain = 0;
+  __syncthreads();
+  {
+    double r1[SPT], r2[SPT];
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < SPT; ++k) {
+      const int i = tid + k * THREADS;
+      ok[k] = i < n;
+      const int ii = ok[k] ? i : 0;
+      s0[k] = c0[ii];
+      r1[k] = Mdl::uses_c1 ? c1[ii] : 0.0;
+      r2[k] = Mdl::uses_c2 ? c2[ii] : 0.0;
+      sx[k] = xs[ii];
+    }
+#pragma unroll
+    for (int k = 0; k < SPT; ++k) {
+      pq[k] = Mdl::template prepare<FAST>(s0[k], r1[k], r2[k]);
+      if (FAST && ok[k] && !Mdl::domain_ok(s0[k], r1[k], r2[k])) bad = true;
+    }
+    if (FAST && bad) bad_domain = 1;  // benign race: every writer stores 1
+  }
+  __syncthreads();
+  if (FAST) {
+    if (bad_domain) {  // log of a non-positive cosine: leave this fit to the exact kernel
+      if (tid == 0) ctx.flags[fit] = kNeedsExact;
+      return;
+    }
+    if (tid == 0) ctx.flags[fit] = 0;
+  }
+
+  // ---- LM state machine in LDS, stepped by lane 0 ---------------------------------------------------------
+  if (tid == 0) {
+    const double *p0 = ctx.p + (size_t)fit * kM;
+    const double *opts = ctx.has_opts ? ctx.opts : nullptr;
+    if constexpr (METHOD == 0)
+      sm.start(p0, n, ctx.itmax, opts, 0, /*speculative=*/0);
+    else
+      sm.start(p0, n, ctx.has_lb ? ctx.lb : nullptr, ctx.has_ub ? ctx.ub : nullptr, nullptr, ctx.itmax, opts, 0);
+  }
+  __syncthreads();
+
+  double hx[SPT], wrk[SPT], jac[SPT][kM];  // dif only: f(p), f(q) and the secant Jacobian rows of this lane's samples
+#pragma unroll
+  for (int k = 0; k < SPT; ++k) {
+    hx[k] = wrk[k] = 0.0;
+    jac[k][0] = jac[k][1] = jac[k][2] = 0.0;
+  }
+
+  for (;;) {
+    const int kind = sm.h.req.kind;
+    if (kind == RQ_DONE) break;
+    if (tid == 0) su.build(sm.h.req);
+    __syncthreads();
+    const PassUniforms<MODEL> &u = su;
+    double acc[kSums];
+#pragma unroll
+    for (int k = 0; k < kSums; ++k) acc[k] = 0.0;
+    double mx = 0.0;
+
+    switch (kind) {
+    case RQ_EVAL:
+#pragma unroll
+      for (int k = 0; k < SPT; ++k) {
+        const double f = model_value<MODEL, FAST>(u, s0[k], pq[k]);
+        const double e = ok[k] ? sx[k] - f : 0.0;
+        acc[0] += e * e;
+        mx = fmax(mx, fabs(e));
+      }
+      block_reduce<1, THREADS>(acc, mx, red, sums);
+      break;
+    case RQ_SCALED:
+#pragma unroll
+      for (int k = 0; k < SPT; ++k) {
+        const double f = model_value<MODEL, FAST>(u, s0[k], pq[k]);
+        const double t = ok[k] ? (sx[k] - f) / u.scal : 0.0;
+        acc[0] += t * t;
+      }
+      block_reduce<1, THREADS>(acc, mx, red, sums);
+      break;
+    case RQ_JAC:
+#pragma unroll
+      for (int k = 0; k < SPT; ++k) {
+        double f0 = 0.0, j[kM];
+        model_fd_row<MODEL, FAST>(u, s0[k], pq[k], true, f0, 0.0, false, j);
+        double e = sx[k] - f0;
+        if (!ok[k]) e = j[0] = j[1] = j[2] = 0.0;
+        acc_normal_eq(j, e, acc, acc + kNL);
+        acc[kNL + kM] += e * e;
+      }
+      block_reduce<SumLayout<kM>::JAC, THREADS>(acc, mx, red, sums);
+      break;
+    case RQ_DIF_INIT:
+#pragma unroll
+      for (int k = 0; k < SPT; ++k) {
+        hx[k] = model_value<MODEL, FAST>(u, s0[k], pq[k]);
+        const double e = ok[k] ? sx[k] - hx[k] : 0.0;
+        acc[0] += e * e;
+      }
+      block_reduce<1, THREADS>(acc, mx, red, sums);
+      break;
+    case RQ_DIF_JAC:
+#pragma unroll
+      for (int k = 0; k < SPT; ++k) {
+        double f0 = 0.0;
+        model_fd_row<MODEL, FAST>(u, s0[k], pq[k], false, f0, hx[k], true, jac[k]);
+        double e = sx[k] - hx[k];
+        if (!ok[k]) e = jac[k][0] = jac[k][1] = jac[k][2] = 0.0;
+        acc_normal_eq(jac[k], e, acc, acc + kNL);
+      }
+      block_reduce<SumLayout<kM>::DIF_JAC, THREADS>(acc, mx, red, sums);
+      break;
+    case RQ_DIF_TRIAL:  // two-step protocol: only f(q) and ||x - f(q)||^2
+#pragma unroll
+      for (int k = 0; k < SPT; ++k) {
+        wrk[k] = model_value_q<MODEL, FAST>(u, s0[k], pq[k]);
+        const double e = ok[k] ? sx[k] - wrk[k] : 0.0;
+        acc[0] += e * e;
+      }
+      block_reduce<1, THREADS>(acc, mx, red, sums);
+      break;
+    case RQ_DIF_UPDATE: {  // Broyden update in registers + normal equations of the updated Jacobian
+      const bool accepted = sm.h.req.aux != 0;
+#pragma unroll
+      for (int k = 0; k < SPT; ++k) {
+        double jn[kM];
+        broyden_row(jac[k], wrk[k], hx[k], u.dp, u.dp_l2, jn);
+        double e = sx[k] - (accepted ? wrk[k] : hx[k]);
+        if (!ok[k]) e = jn[0] = jn[1] = jn[2] = 0.0;
+        jac[k][0] = jn[0];
+        jac[k][1] = jn[1];
+        jac[k][2] = jn[2];
+        if (accepted) hx[k] = wrk[k];
+        acc_normal_eq(jn, e, acc, acc + kNL);
+      }
+      block_reduce<SumLayout<kM>::DIF_JAC, THREADS>(acc, mx, red, sums);
+      break;
+    }
+    default: break;
+    }
+    if (tid == 0) sm.step(sums, sums[kSums]);
+    __syncthreads();
+  }
+
+  if (tid == 0) {
+    double *po = ctx.p + (size_t)fit * kM;
+    for (int i = 0; i < kM; ++i) po[i] = sm.h.p[i];
+    if (ctx.info)
+      for (int i = 0; i < kInfoSz; ++i) ctx.info[(size_t)fit * kInfoSz + i] = sm.c.info[i];
+    if (ctx.ret) ctx.ret[fit] = sm.c.ret;
+  }
 }
+
+// ---------------------------------------------------------------------------------------------------
+// synthetic sample generator (bench support): the counter stream of brdf_amd/synth.py on the device
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double synth_uniform(unsigned long long seed, unsigned long long index) {
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ULL * (index + 1ULL);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  z = z ^ (z >> 31);
+  return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+
+template <int MODEL>
+__global__ __launch_bounds__(256) void synth_kernel(unsigned long long seed, long long first, int count, int n,
+                                                    const double *__restrict__ truth, double *__restrict__ angles,
+                                                    double *__restrict__ x) {
+  using Mdl = BrdfModel<MODEL>;
+  const long long total = (long long)count * n;
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+    const long long s = g / n;
+    const int i = (int)(g - s * n);
+    const unsigned long long base = (unsigned long long)(first + s) * 4ULL;
+    double c[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      c[k] = 0.05 + 0.95 * synth_uniform(seed, (base + k) * (unsigned long long)n + i);
+      angles[((size_t)s * 3 + k) * n + i] = c[k];
+    }
+    const double p[kM] = {truth[s * 3 + 0], truth[s * 3 + 1], truth[s * 3 + 2]};
+    const Lin l = Mdl::lin(p);
+    const Nl nl = Mdl::nl(p);
+    const double f = Mdl::combine(l, c[0], Mdl::template shape<false>(nl, c[0], Mdl::template prepare<false>(c[0], c[1], c[2])));
+    x[(size_t)s * n + i] = f + 0.01 * (synth_uniform(seed, (base + 3) * (unsigned long long)n + i) - 0.5);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+namespace {
+
+using BatchFn = void (*)(BatchCtx);
+
+template <int THREADS, int SPT>
+BatchFn pick(int model, int method, bool fast) {
+  static const BatchFn table[2][MODEL_COUNT][2] = {
+      {{batch_fit_kernel<0, 0, false, THREADS, SPT>, batch_fit_kernel<0, 1, false, THREADS, SPT>},
+       {batch_fit_kernel<1, 0, false, THREADS, SPT>, batch_fit_kernel<1, 1, false, THREADS, SPT>},
+       {nullptr, nullptr}},  // Ward's prepared path has no domain restriction: no exact twin needed
+      {{batch_fit_kernel<0, 0, true, THREADS, SPT>, batch_fit_kernel<0, 1, true, THREADS, SPT>},
+       {batch_fit_kernel<1, 0, true, THREADS, SPT>, batch_fit_kernel<1, 1, true, THREADS, SPT>},
+       {batch_fit_kernel<2, 0, true, THREADS, SPT>, batch_fit_kernel<2, 1, true, THREADS, SPT>}},
+  };
+  return table[fast ? 1 : 0][model][method];
+}
+
+struct Geometry {
+  int threads, spt;
+};
+// one wavefront per fit up to 256 samples, one workgroup per fit up to 4096
+bool geometry_for(int n, Geometry *g) {
+  if (n <= 64) *g = {64, 1};
+  else if (n <= 256) *g = {64, 4};
+  else if (n <= 1024) *g = {256, 4};
+  else if (n <= 4096) *g = {512, 8};
+  else return false;
+  return true;
+}
+
+BatchFn kernel_for(const Geometry &g, int model, int method, bool fast) {
+  if (g.threads == 64 && g.spt == 1) return pick<64, 1>(model, method, fast);
+  if (g.threads == 64 && g.spt == 4) return pick<64, 4>(model, method, fast);
+  if (g.threads == 256) return pick<256, 4>(model, method, fast);
+  return pick<512, 8>(model, method, fast);
+}
+
+struct FlagBuf {
+  int *ptr = nullptr;
+  size_t cap = 0;
+  int device = -1;
+};
+thread_local FlagBuf g_flags;
+
+}  // namespace
+
+#define HIP_OK(call)                                                                  \
+  do {                                                                                \
+    hipError_t e_ = (call);                                                           \
+    if (e_ != hipSuccess) {                                                           \
+      set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return kLmError;                                                                \
+    }                                                                                 \
+  } while (0)
+
+int batch_fit_enqueue(const BatchFitArgs &a) {
+  if (a.model < 0 || a.model >= MODEL_COUNT || (a.method != 0 && a.method != 1)) {
+    set_error("brdf_hip_fit_batch_dev(): unknown model %d / method %d", a.model, a.method);
+    return kLmError;
+  }
+  if (!a.d_angles || !a.d_x || !a.d_p || a.S <= 0 || a.n <= 0) {
+    set_error("brdf_hip_fit_batch_dev(): null device pointer or non-positive S/n");
+    return kLmError;
+  }
+  Geometry g;
+  if (!geometry_for(a.n, &g)) {
+    set_error("brdf_hip_fit_batch_dev(): n = %d exceeds the register-resident limit of 4096 samples per fit; "
+              "use brdf_hip_fit_dev (streamed regime) for large fits",
+              a.n);
+    return kLmError;
+  }
+  (void)hipGetLastError();
+  int dev = 0;
+  HIP_OK(hipGetDevice(&dev));
+  FlagBuf &fb = g_flags;
+  if (fb.device != dev || fb.cap < (size_t)a.S) {
+    if (fb.ptr) {
+      HIP_OK(hipDeviceSynchronize());  // a previous batch on another stream may still read the old buffer
+      (void)hipFree(fb.ptr);
+      fb.ptr = nullptr;
+      fb.cap = 0;
+    }
+    HIP_OK(hipMalloc(&fb.ptr, sizeof(int) * (size_t)a.S));
+    fb.cap = (size_t)a.S;
+    fb.device = dev;
+  }
+
+  BatchCtx c;
+  memset(&c, 0, sizeof c);
+  c.angles = a.d_angles;
+  c.x = a.d_x;
+  c.p = a.d_p;
+  c.info = a.d_info;
+  c.ret = a.d_ret;
+  c.flags = fb.ptr;
+  c.S = a.S;
+  c.n = a.n;
+  c.itmax = a.itmax;
+  c.has_opts = a.opts != nullptr;
+  c.has_lb = a.lb != nullptr;
+  c.has_ub = a.ub != nullptr;
+  for (int i = 0; i < 5; ++i) c.opts[i] = a.opts ? a.opts[i] : 0.0;
+  for (int i = 0; i < kM; ++i) {
+    c.lb[i] = a.lb ? a.lb[i] : 0.0;
+    c.ub[i] = a.ub ? a.ub[i] : 0.0;
+  }
+  if (a.method == 1 && a.lb && a.ub)
+    for (int i = 0; i < kM; ++i)
+      if (a.lb[i] > a.ub[i]) {  // lmbc_core.c:451-454
+        set_error("dlevmar_bc_dif(): at least one lower bound exceeds the upper one");
+        return kLmError;
+      }
+
+  const bool fast = brdf_fast_path_enabled() || a.model == MODEL_WARD;
+  const dim3 grid(a.S), block(g.threads);
+  if (fast) {
+    hipLaunchKernelGGL(kernel_for(g, a.model, a.method, true), grid, block, 0, a.stream, c);
+    HIP_OK(hipGetLastError());
+    if (a.model != MODEL_WARD) {  // fits with a cosine <= 0 marked themselves: second launch on the exact path
+      hipLaunchKernelGGL(kernel_for(g, a.model, a.method, false), grid, block, 0, a.stream, c);
+      HIP_OK(hipGetLastError());
+    }
+  } else {
+    // BRDF_HIP_EXACT_POW=1: mark every fit for the exact kernel
+    HIP_OK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(fb.ptr), kNeedsExact, (size_t)a.S, a.stream));
+    hipLaunchKernelGGL(kernel_for(g, a.model, a.method, false), grid, block, 0, a.stream, c);
+    HIP_OK(hipGetLastError());
+  }
+  return 0;
+}
+
+int synth_enqueue(int model, unsigned long long seed, long long first, int count, int n, const double *d_truth,
+                  double *d_angles, double *d_x, hipStream_t stream) {
+  if (model < 0 || model >= MODEL_COUNT || !d_truth || !d_angles || !d_x || count <= 0 || n <= 0) {
+    set_error("brdf_hip_synth_dev(): bad arguments");
+    return kLmError;
+  }
+  (void)hipGetLastError();
+  const long long total = (long long)count * n;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  switch (model) {
+  case 0: hipLaunchKernelGGL(synth_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, stream, seed, first, count, n, d_truth, d_angles, d_x); break;
+  case 1: hipLaunchKernelGGL(synth_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, stream, seed, first, count, n, d_truth, d_angles, d_x); break;
+  default: hipLaunchKernelGGL(synth_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, stream, seed, first, count, n, d_truth, d_angles, d_x); break;
+  }
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace brdf

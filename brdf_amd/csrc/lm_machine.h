@@ -49,8 +49,11 @@ enum ReqKind : int {
   RQ_JAC = 3,        // FD Jacobian at p, nothing stored: sums = [JtJ lower (row-major), Jte, sum e^2]
   RQ_DIF_INIT = 4,   // hx[sel_hx] <- f(p); sums[0] = sum e^2
   RQ_DIF_JAC = 5,    // FD Jacobian at p from hx[sel_hx]; J[sel_j] <- J; sums = [JtJ lower, Jte]
-  RQ_DIF_TRIAL = 6   // hx[!sel_hx] <- f(q); J[!sel_j] <- Broyden(J[sel_j]); sums = [sum e_new^2,
+  RQ_DIF_TRIAL = 6,  // speculative:  hx[!sel_hx] <- f(q); J[!sel_j] <- Broyden(J[sel_j]); sums = [sum e_new^2,
                      //   JnTJn lower, JnT e_new, JnT e_old]
+                     // two-step:     wrk <- f(q); sums = [sum e_new^2]
+  RQ_DIF_UPDATE = 7  // two-step only: J <- Broyden(J, wrk, hx); sums = [JTJ lower, JT e] with e = x-wrk if
+                     //   aux (step accepted) else x-hx; finally hx <- wrk if aux
 };
 
 template <int M>
@@ -59,6 +62,7 @@ struct Request {
   int central;  // RQ_JAC / RQ_DIF_JAC: 0 forward, 1 central differences
   int sel_hx;   // which of the two hx buffers holds f(current p)     (dif only)
   int sel_j;    // which of the two Jacobian buffers is current       (dif only)
+  int aux;      // RQ_DIF_UPDATE: 1 if the trial step was accepted
   double p[M];  // evaluation point / Jacobian base point
   double d[M];  // finite-difference steps                            (misc_core.c:155-158)
   double q[M];  // trial point p+Dp                                   (RQ_DIF_TRIAL)
@@ -251,19 +255,23 @@ LM_HD FitOptions make_options(const double *opts) {
 // =================================================================================================
 template <int M>
 struct DifMachine {
-  enum Phase : int { D_INIT_EVAL = 1, D_ITER_TOP, D_AFTER_JAC, D_GRADIENT, D_SOLVE, D_AFTER_TRIAL, D_REJECT, D_FINISH, D_DONE };
+  enum Phase : int { D_INIT_EVAL = 1, D_ITER_TOP, D_AFTER_JAC, D_GRADIENT, D_SOLVE, D_AFTER_TRIAL, D_AFTER_UPDATE, D_DECIDE, D_REJECT, D_FINISH, D_DONE };
   // Cold: configuration and results, touched at start/finish only.  Hot: everything an LM step reads or
   // writes.  (Measured on gfx950: running the step on a register copy of Hot makes hipcc spill to scratch
   // and is slower than stepping in place in LDS, so step() works in place.)
   struct Cold {
     FitOptions o;
     int itmax, n, want_covar, refresh;
+    int speculative;  // 1: the trial pass also produces the Broyden-updated Jacobian and its products
+                      //    (one pass per LM iteration; needs double-buffered J/hx -- streamed regime)
+                      // 0: trial pass, decision, then an update pass (per-sample state stays single-buffered in
+                      //    registers -- batched regime, where a pass is only a workgroup-wide reduction)
     double info[kInfoSz], covar[M * M];
     int ret;
   };
   struct Hot {
     int phase, k, stop, nu, nfev, njap, nlss, updjac, updp, newjac;
-    int sel_hx, sel_j;
+    int sel_hx, sel_j, accepted;
     double p[M], mu, p_e2, init_e2, jte_inf, p_l2, dp_l2, pdp_e2;
     double jtj[M * M], jte[M], diag[M], dp[M], pdp[M];
     double spec_jtj[M * M], spec_jte[M];  // normal equations of the Broyden-updated J, adopted lazily
@@ -272,8 +280,10 @@ struct DifMachine {
   Cold c;
   Hot h;
 
-  LM_HD void start(const double *p0, int n_, int itmax_, const double *opts, int want_covar_) {
+  LM_HD void start(const double *p0, int n_, int itmax_, const double *opts, int want_covar_, int speculative_ = 1) {
     c.o = make_options(opts);
+    c.speculative = speculative_;
+    h.accepted = 0;
     c.itmax = itmax_;
     c.n = n_;
     c.want_covar = want_covar_;
@@ -312,6 +322,7 @@ struct DifMachine {
     h.req.central = 0;
     h.req.sel_hx = h.sel_hx;
     h.req.sel_j = h.sel_j;
+    h.req.aux = 0;
     h.req.dp_l2 = 0.0;
     h.req.scal = 1.0;
     for (int i = 0; i < M; ++i) h.req.p[i] = h.req.d[i] = h.req.q[i] = h.req.dp[i] = 0.0;
@@ -445,27 +456,53 @@ struct DifMachine {
         }
         const double dF = h.p_e2 - h.pdp_e2;
         const bool updated = (h.updp || dF > 0);
-        if (updated) {  // adopt the speculatively updated Jacobian
-          h.sel_j ^= 1;
-          ++h.updjac;
-          h.newjac = 1;
-        }
         double dL = 0.0;
         for (int i = 0; i < M; ++i) dL += h.dp[i] * (h.mu * h.dp[i] + h.jte[i]);
-        const bool accepted = (dL > 0.0 && dF > 0.0);
-        if (updated) {  // keep the updated Jacobian's products, paired with the residual that stays live;
-                        // they replace jtj/jte at the top of the next iteration, as in the reference
-          unpack_lower<M>(s + 1, h.spec_jtj);
-          const double *g = s + 1 + SumLayout<M>::NL + (accepted ? 0 : M);
-          for (int i = 0; i < M; ++i) h.spec_jte[i] = g[i];
-        }
-        if (accepted) {
+        h.accepted = (dL > 0.0 && dF > 0.0) ? 1 : 0;
+        if (h.accepted) {  // damping update uses dF, dL of this step: do it now, they are not kept
           double t = (2.0 * dF / dL - 1.0);
           t = 1.0 - t * t * t;
           h.mu = h.mu * ((t >= kOneThird) ? t : kOneThird);
+        }
+        if (updated) {
+          ++h.updjac;
+          h.newjac = 1;
+          if (c.speculative) {  // adopt the speculatively updated Jacobian; keep its products, paired with the
+                                // residual that stays live -- they replace jtj/jte at the top of the next
+                                // iteration, as in the reference
+            h.sel_j ^= 1;
+            unpack_lower<M>(s + 1, h.spec_jtj);
+            const double *g = s + 1 + SumLayout<M>::NL + (h.accepted ? 0 : M);
+            for (int i = 0; i < M; ++i) h.spec_jte[i] = g[i];
+          } else {
+            clear_req(h);
+            h.req.kind = RQ_DIF_UPDATE;
+            h.req.aux = h.accepted;
+            for (int i = 0; i < M; ++i) {
+              h.req.p[i] = h.p[i];
+              h.req.q[i] = h.pdp[i];
+              h.req.dp[i] = h.dp[i];
+            }
+            h.req.dp_l2 = h.dp_l2;
+            h.phase = D_AFTER_UPDATE;
+            return;
+          }
+        }
+        h.phase = D_DECIDE;
+        break;
+      }
+
+      case D_AFTER_UPDATE:
+        unpack_lower<M>(s, h.spec_jtj);
+        for (int i = 0; i < M; ++i) h.spec_jte[i] = s[SumLayout<M>::NL + i];
+        h.phase = D_DECIDE;
+        break;
+
+      case D_DECIDE:
+        if (h.accepted) {
           h.nu = 2;
           for (int i = 0; i < M; ++i) h.p[i] = h.pdp[i];
-          h.sel_hx ^= 1;  // e, hx <- trial values
+          if (c.speculative) h.sel_hx ^= 1;  // e, hx <- trial values
           h.p_e2 = h.pdp_e2;
           h.updp = 1;
           ++h.k;
@@ -474,7 +511,6 @@ struct DifMachine {
         }
         h.phase = D_REJECT;
         break;
-      }
 
       case D_REJECT: {  // lm_core.c:797-806
         h.mu *= h.nu;
@@ -575,7 +611,7 @@ struct BcMachine {
   static LM_HD void clear_req(Hot &h) {
     h.req.kind = RQ_DONE;
     h.req.central = 0;
-    h.req.sel_hx = h.req.sel_j = 0;
+    h.req.sel_hx = h.req.sel_j = h.req.aux = 0;
     h.req.dp_l2 = 0.0;
     h.req.scal = 1.0;
     for (int i = 0; i < M; ++i) h.req.p[i] = h.req.d[i] = h.req.q[i] = h.req.dp[i] = 0.0;

@@ -75,6 +75,7 @@ struct FitStats {
 };
 FitStats stream_fit_last_stats();
 
+bool brdf_fast_path_enabled();  // false when BRDF_HIP_EXACT_POW=1
 void set_error(const char *fmt, ...);
 const char *get_error();
 

@@ -30,8 +30,15 @@ P0 = {0: (0.5, 1.0, 1.0), 1: (0.5, 1.0, 1.0), 2: (0.5, 0.5, 0.3)}
 TRUTH = {0: (0.35, 0.6, 24.0), 1: (0.35, 0.6, 24.0), 2: (0.35, 0.25, 0.15)}
 OPTS = (1e-3, 1e-15, 1e-15, 1e-20, 1e-6)
 ITMAX = 100
-LB = (0.0, 0.0, 0.0)
+LB = (0.0, 0.0, 0.0)  # the application's box, brdfdata.cpp:1112-1113
 UB = (100.0, 100.0, 100.0)
+
+
+def bounds(model: int):
+    """Box for the multi-surfel configurations.  Phong/Blinn-Phong: the application's [0,100]^3.  Ward divides
+    by alpha^2, so a projected step that lands exactly on alpha = 0 turns the model into NaN and levmar (the
+    reference's as much as this build's) stops with reason 7 / LM_ERROR; its roughness is kept >= 0.01."""
+    return ((0.0, 0.0, 0.01), UB) if model == 2 else (LB, UB)
 
 
 def uniform(seed: int, index: np.ndarray) -> np.ndarray:

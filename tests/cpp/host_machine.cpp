@@ -17,6 +17,8 @@ using namespace brdf;
 
 namespace {
 
+int g_speculative = 1;  // dif protocol under test (see lm_machine.h)
+
 template <int MODEL, bool FAST>
 struct HostPasses {
   using Mdl = BrdfModel<MODEL>;
@@ -24,7 +26,7 @@ struct HostPasses {
   // path the GPU kernels use (cached log / tan^2 / rsqrt), here with host libm.
   Prep prep(int i) const { return Mdl::template prepare<FAST>(c0[i], c1[i], c2[i]); }
   const double *c0, *c1, *c2, *x;
-  int n, bc_rule;
+  int n, bc_rule, speculative = 1;
   std::vector<double> e, e2, jac, hx[2], J[2];
 
   HostPasses(const double *angles, const double *x_, int n_, int bc)
@@ -95,6 +97,11 @@ struct HostPasses {
       break;
     }
     case RQ_DIF_TRIAL: {
+      if (!speculative) {  // two-step protocol: wrk only
+        for (int i = 0; i < n; ++i) hx[1][i] = model_value_q<MODEL, FAST>(u, c0[i], prep(i));
+        s[0] = orc_l2_residual(e2.data(), x, hx[1].data(), n);
+        break;
+      }
       std::vector<double> &h = hx[r.sel_hx];
       std::vector<double> &hn = hx[r.sel_hx ^ 1];
       std::vector<double> &Jc = J[r.sel_j];
@@ -112,6 +119,22 @@ struct HostPasses {
       for (int i = 0; i < 3; ++i) s[1 + SumLayout<3>::NL + 3 + i] = jte[i];
       break;
     }
+    case RQ_DIF_UPDATE: {  // two-step protocol: hx[0] = f(p), hx[1] = wrk = f(q) of the preceding trial pass
+      std::vector<double> &h = hx[0];
+      std::vector<double> &w = hx[1];
+      std::vector<double> &Jc = J[0];
+      for (int i = 0; i < n; ++i) {
+        double jn[3];
+        broyden_row(&Jc[3 * i], w[i], h[i], u.dp, u.dp_l2, jn);
+        for (int j = 0; j < 3; ++j) Jc[3 * i + j] = jn[j];
+        e[i] = x[i] - (r.aux ? w[i] : h[i]);
+        if (r.aux) h[i] = w[i];
+      }
+      orc_jtj_jte(Jc.data(), e.data(), jtj, jte, n, 3, 0);
+      pack_lower(jtj, s);
+      for (int i = 0; i < 3; ++i) s[SumLayout<3>::NL + i] = jte[i];
+      break;
+    }
     default:
       break;
     }
@@ -126,8 +149,9 @@ int fit(int method, double *angles, double *x, int n, double *p, int itmax, doub
   int np = 0;
   if (method == 0) {
     HostPasses<MODEL, FAST> hp(angles, x, n, 0);
+    hp.speculative = g_speculative;
     DifMachine<3> m;
-    m.start(p, n, itmax, opts, covar != nullptr);
+    m.start(p, n, itmax, opts, covar != nullptr, g_speculative);
     while (m.h.req.kind != RQ_DONE) {
       hp.run(m.h.req, s, mx);
       ++np;
@@ -178,3 +202,5 @@ extern "C" int hm_brdf_fit_fast(int method, int model, double *angles, double *x
   }
   return -1;
 }
+
+extern "C" void hm_set_dif_protocol(int speculative) { g_speculative = speculative; }

@@ -123,3 +123,19 @@ def test_prepared_sample_path_matches_oracle_within_tolerance(method, model):
         assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
     else:
         assert b[0] >= 0 and L.rel_err(b[1], a[1]) <= 1e-7 and abs(b[2][1] - a[2][1]) <= 1e-10 * a[2][1]
+
+
+def test_two_step_dif_protocol_is_bit_exact_too():
+    """the batched GPU kernels run dlevmar_dif's Broyden update as a separate pass after the accept/reject
+    decision (lm_machine.h, speculative = 0); same trajectory as the reference, bit for bit"""
+    L.hm.hm_set_dif_protocol(0)
+    try:
+        for f in FITS:
+            if f["method"] != 0:
+                continue
+            angles, x, _ = synth.make_single(f["model"], f["n"])
+            r, p, info = L.brdf_fit("hm", 0, f["model"], angles, x, synth.P0[f["model"]], synth.ITMAX, synth.OPTS,
+                                    synth.LB, synth.UB)
+            assert r == f["ret"] and np.array_equal(p, _hex(f["p"])) and np.array_equal(info, _hex(f["info"]))
+    finally:
+        L.hm.hm_set_dif_protocol(1)
