@@ -130,9 +130,13 @@ struct PassUniforms {
   double dp[kM], dp_l2, scal;
   int central;
 
+  // only what the request kind reads is computed (each lin()/nl() hides an fp64 division or two, and on the
+  // device this runs on a single lane between two passes)
   LM_HD void build(const Request<kM> &r) {
-    l0 = Mdl::lin(r.p);
-    n0 = Mdl::nl(r.p);
+    if (r.kind != RQ_DIF_TRIAL && r.kind != RQ_DIF_UPDATE) {
+      l0 = Mdl::lin(r.p);
+      n0 = Mdl::nl(r.p);
+    }
     central = r.central;
     scal = r.scal;
     dp_l2 = r.dp_l2;
@@ -150,7 +154,7 @@ struct PassUniforms {
         dinv[j] = (r.central ? 0.5 : 1.0) / r.d[j];
       }
     }
-    if (r.kind == RQ_DIF_TRIAL) {
+    if (r.kind == RQ_DIF_TRIAL) {  // (RQ_DIF_UPDATE needs dp, dp_l2 only)
       lq = Mdl::lin(r.q);
       nq = Mdl::nl(r.q);
     }

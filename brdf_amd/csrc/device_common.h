@@ -45,56 +45,73 @@ __device__ __forceinline__ double wave_reduce_to_last(double v) {
   return v;
 }
 
-// Workgroup reduction of NS sums and one max: DPP tree inside each wave, the last lane of every wave
-// parks its value in LDS, NS+1 threads fold the per-wave values in wave order.  Two barriers.  The order
-// is a pure function of (THREADS, NS): results are reproducible run to run.
-// out[0..NS) receive the sums, out[kSums] the max; visible to all threads on return.
+// Workgroup reduction of NS sums and one max.  The order is a pure function of (THREADS, NS): results are
+// reproducible run to run.  out[0..NS) receive the sums, out[kSums] the max; visible to all threads on return.
+//
+//  NS == 1 (the common evaluation pass): DPP tree inside each wave, the last lane of every wave parks its
+//           value in LDS, two threads fold the per-wave values in wave order.
+//  NS  > 1 (Jacobian / Broyden passes, 9..13 sums): a DPP chain per value per wave would serialise ~14 dependent
+//           chains in every wave, so the values are transposed through LDS instead: every thread parks its NS+1
+//           values as buf[slot][thread]; then wave w owns slots {w, w+NW, ..}: each lane adds THREADS/64 entries
+//           of the slot in a fixed order and ONE DPP tree per slot finishes it.
 template <int THREADS>
-constexpr int reduce_buf_doubles() { return kSlots * (THREADS / kWave); }
+constexpr int reduce_buf_doubles() { return kSlots * THREADS; }
 
 template <int NS, int THREADS>
 __device__ __forceinline__ void block_reduce(const double *acc, double mx, double *buf, double *out) {
   constexpr int NW = THREADS / kWave;
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
+  if constexpr (NS == 1) {
+    const double v = wave_reduce_to_last<OpSum>(acc[0]);
+    const double m = wave_reduce_to_last<OpMax>(mx);
+    if (lane == kWave - 1) {
+      buf[wave] = v;
+      buf[NW + wave] = m;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double s = buf[0];
 #pragma unroll
-  for (int k = 0; k < NS; ++k) {
-    const double v = wave_reduce_to_last<OpSum>(acc[k]);
-    if (lane == kWave - 1) buf[k * NW + wave] = v;
-  }
-  {
-    const double v = wave_reduce_to_last<OpMax>(mx);
-    if (lane == kWave - 1) buf[kSums * NW + wave] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x < NS) {
-    const double *src = buf + threadIdx.x * NW;
-    double s = src[0];
+      for (int w = 1; w < NW; ++w) s += buf[w];
+      out[0] = s;
+    } else if (threadIdx.x == kWave) {  // a lane of the second wave when there is one (any thread would do)
+      double s = buf[NW];
 #pragma unroll
-    for (int w = 1; w < NW; ++w) s += src[w];
-    out[threadIdx.x] = s;
-  } else if (threadIdx.x == kSums) {
-    const double *src = buf + kSums * NW;
-    double s = src[0];
+      for (int w = 1; w < NW; ++w) s = fmax(s, buf[NW + w]);
+      out[kSums] = s;
+    }
+    if (NW == 1 && threadIdx.x == 0) out[kSums] = buf[NW];
+    __syncthreads();
+  } else {
 #pragma unroll
-    for (int w = 1; w < NW; ++w) s = fmax(s, src[w]);
-    out[kSums] = s;
+    for (int k = 0; k < NS; ++k) buf[k * THREADS + threadIdx.x] = acc[k];
+    buf[NS * THREADS + threadIdx.x] = mx;
+    __syncthreads();
+    for (int k = wave; k <= NS; k += NW) {  // wave-uniform loop: slot k belongs to this wave
+      const double *src = buf + k * THREADS + lane;
+      double s = src[0];
+      if (k < NS) {
+#pragma unroll
+        for (int j = 1; j < NW; ++j) s += src[j * kWave];
+        s = wave_reduce_to_last<OpSum>(s);
+        if (lane == kWave - 1) out[k] = s;
+      } else {
+#pragma unroll
+        for (int j = 1; j < NW; ++j) s = fmax(s, src[j * kWave]);
+        s = wave_reduce_to_last<OpMax>(s);
+        if (lane == kWave - 1) out[kSums] = s;
+      }
+    }
+    __syncthreads();
   }
-  __syncthreads();
 }
 
-// Same tree over `count` (<= THREADS) per-workgroup partial rows that already sit in global memory:
-// part[slot * row_stride + b], b < count.  Every thread issues its NS+1 loads up front so the fold
-// pays ONE global-memory round trip (the rows were written by other CUs in the previous launch and
-// miss in this CU's L1/L2), then the LDS tree of block_reduce takes over.
+// The same over `count` (<= THREADS) per-workgroup partial rows of the previous launch, already loaded by the
+// caller (one value per slot per thread, zero beyond `count`).
 template <int NS, int THREADS>
-__device__ __forceinline__ void fold_rows(const double *part, int row_stride, int count, double *buf, double *out) {
-  const int t = threadIdx.x;
-  double v[NS + 1];
-#pragma unroll
-  for (int k = 0; k < NS; ++k) v[k] = (t < count) ? part[(size_t)k * row_stride + t] : 0.0;
-  v[NS] = (t < count) ? part[(size_t)kSums * row_stride + t] : 0.0;
-  block_reduce<NS, THREADS>(v, v[NS], buf, out);
+__device__ __forceinline__ void fold_rows(const double *v, double *buf, double *out) {
+  block_reduce<NS, THREADS>(v, v[kSums], buf, out);
 }
 
 // number of sum slots a request kind produces

@@ -341,25 +341,26 @@ struct DifMachine {
   LM_HD void step(const double *s, double maxabs) { run(c, h, s, maxabs); }
 
   static LM_HD void run(Cold &c, Hot &h, const double *s, double /*maxabs*/) {
+    int ph = h.phase;  // kept in a register: phase transitions become direct jumps, not LDS round trips
     for (;;) {
-      switch (h.phase) {
+      switch (ph) {
       case D_INIT_EVAL:  // lm_core.c:551-564
         h.nfev = 1;
         h.p_e2 = s[0];
         h.init_e2 = h.p_e2;
         if (!lm_finite(h.p_e2)) h.stop = 7;
         h.nu = 20;
-        h.phase = D_ITER_TOP;
+        ph = D_ITER_TOP;
         break;
 
       case D_ITER_TOP:
         if (!(h.k < c.itmax && !h.stop)) {
-          h.phase = D_FINISH;
+          ph = D_FINISH;
           break;
         }
         if (h.p_e2 <= c.o.eps3) {
           h.stop = 6;
-          h.phase = D_FINISH;
+          ph = D_FINISH;
           break;
         }
         if ((h.updp && h.nu > 16) || h.updjac == c.refresh) {  // fresh FD Jacobian, lm_core.c:578-588
@@ -374,10 +375,10 @@ struct DifMachine {
           h.updjac = 0;
           h.updp = 0;
           h.newjac = 1;
-          h.phase = D_AFTER_JAC;
-          return;
+          ph = D_AFTER_JAC;
+          { h.phase = ph; return; }
         }
-        h.phase = D_GRADIENT;
+        ph = D_GRADIENT;
         break;
 
       case D_AFTER_JAC:
@@ -385,7 +386,7 @@ struct DifMachine {
         for (int i = 0; i < M; ++i) h.jte[i] = s[SumLayout<M>::NL + i];
         h.newjac = 0;
         gradient_stats(h);
-        h.phase = D_SOLVE;
+        ph = D_SOLVE;
         break;
 
       case D_GRADIENT:
@@ -395,14 +396,14 @@ struct DifMachine {
           for (int i = 0; i < M; ++i) h.jte[i] = h.spec_jte[i];
           gradient_stats(h);
         }
-        h.phase = D_SOLVE;
+        ph = D_SOLVE;
         break;
 
       case D_SOLVE: {
         if (h.jte_inf <= c.o.eps1) {  // lm_core.c:676-680
           h.dp_l2 = 0.0;
           h.stop = 1;
-          h.phase = D_FINISH;
+          ph = D_FINISH;
           break;
         }
         if (h.k == 0) {  // lm_core.c:683-687
@@ -415,7 +416,7 @@ struct DifMachine {
         const int solved = lu_solve<M>(h.jtj, h.jte, h.dp);
         ++h.nlss;
         if (!solved) {
-          h.phase = D_REJECT;
+          ph = D_REJECT;
           break;
         }
         h.dp_l2 = 0.0;
@@ -426,12 +427,12 @@ struct DifMachine {
         }
         if (h.dp_l2 <= c.o.eps2sq * h.p_l2) {
           h.stop = 2;
-          h.phase = D_FINISH;
+          ph = D_FINISH;
           break;
         }
         if (h.dp_l2 >= (h.p_l2 + c.o.eps2) / (kEpsilon * kEpsilon)) {
           h.stop = 4;
-          h.phase = D_FINISH;
+          ph = D_FINISH;
           break;
         }
         clear_req(h);
@@ -443,15 +444,15 @@ struct DifMachine {
         }
         h.req.dp_l2 = h.dp_l2;
         ++h.nfev;
-        h.phase = D_AFTER_TRIAL;
-        return;
+        ph = D_AFTER_TRIAL;
+        { h.phase = ph; return; }
       }
 
       case D_AFTER_TRIAL: {  // lm_core.c:742-790
         h.pdp_e2 = s[0];
         if (!lm_finite(h.pdp_e2)) {
           h.stop = 7;
-          h.phase = D_FINISH;
+          ph = D_FINISH;
           break;
         }
         const double dF = h.p_e2 - h.pdp_e2;
@@ -484,18 +485,18 @@ struct DifMachine {
               h.req.dp[i] = h.dp[i];
             }
             h.req.dp_l2 = h.dp_l2;
-            h.phase = D_AFTER_UPDATE;
-            return;
+            ph = D_AFTER_UPDATE;
+            { h.phase = ph; return; }
           }
         }
-        h.phase = D_DECIDE;
+        ph = D_DECIDE;
         break;
       }
 
       case D_AFTER_UPDATE:
         unpack_lower<M>(s, h.spec_jtj);
         for (int i = 0; i < M; ++i) h.spec_jte[i] = s[SumLayout<M>::NL + i];
-        h.phase = D_DECIDE;
+        ph = D_DECIDE;
         break;
 
       case D_DECIDE:
@@ -506,10 +507,10 @@ struct DifMachine {
           h.p_e2 = h.pdp_e2;
           h.updp = 1;
           ++h.k;
-          h.phase = D_ITER_TOP;
+          ph = D_ITER_TOP;
           break;
         }
-        h.phase = D_REJECT;
+        ph = D_REJECT;
         break;
 
       case D_REJECT: {  // lm_core.c:797-806
@@ -517,13 +518,13 @@ struct DifMachine {
         const int nu2 = (int)((unsigned)h.nu << 1);
         if (nu2 <= h.nu) {
           h.stop = 5;
-          h.phase = D_FINISH;
+          ph = D_FINISH;
           break;
         }
         h.nu = nu2;
         for (int i = 0; i < M; ++i) h.jtj[i * M + i] = h.diag[i];
         ++h.k;
-        h.phase = D_ITER_TOP;
+        ph = D_ITER_TOP;
         break;
       }
 
@@ -546,13 +547,13 @@ struct DifMachine {
         if (c.want_covar) lu_covar<M>(h.jtj, c.covar, h.p_e2, c.n);
         c.ret = (h.stop != 4 && h.stop != 7) ? h.k : kLmError;
         clear_req(h);
-        h.phase = D_DONE;
-        return;
+        ph = D_DONE;
+        { h.phase = ph; return; }
       }
 
       default:
         h.req.kind = RQ_DONE;
-        return;
+        { h.phase = ph; return; }
       }
     }
   }
@@ -697,8 +698,9 @@ struct BcMachine {
 
   static LM_HD void run(Cold &c, Hot &h, const double *s, double maxabs) {
     constexpr double alpha = 1e-4, beta = 0.9, gamma = 0.99995, rho = 1e-8, tming = 1e-18, tini = 1.0;
+    int ph = h.phase;  // kept in a register: phase transitions become direct jumps, not LDS round trips
     for (;;) {
-      switch (h.phase) {
+      switch (ph) {
       case B_INIT_EVAL:  // lmbc_core.c:523-540
         h.nfev = 1;
         h.p_e2 = s[0];
@@ -710,17 +712,17 @@ struct BcMachine {
             if (c.has_ub && c.ub[i] != DBL_MAX) c.ub[i] = c.ub[i] / c.dscl[i];
             if (c.has_lb && c.lb[i] != -DBL_MAX) c.lb[i] = c.lb[i] / c.dscl[i];
           }
-        h.phase = B_ITER_TOP;
+        ph = B_ITER_TOP;
         break;
 
       case B_ITER_TOP: {
         if (!(h.k < c.itmax && !h.stop)) {
-          h.phase = B_FINISH;
+          ph = B_FINISH;
           break;
         }
         if (h.p_e2 <= c.o.eps3) {
           h.stop = 6;
-          h.phase = B_FINISH;
+          ph = B_FINISH;
           break;
         }
         clear_req(h);  // FD Jacobian at the unscaled point, lmbc_core.c:555-561 + :1043-1054
@@ -729,8 +731,8 @@ struct BcMachine {
         for (int i = 0; i < M; ++i) h.req.p[i] = c.has_dscl ? h.p[i] * c.dscl[i] : h.p[i];
         fd_steps<M>(h.req.p, c.o.delta, h.req.d);
         ++h.njev;
-        h.phase = B_AFTER_JAC;
-        return;
+        ph = B_AFTER_JAC;
+        { h.phase = ph; return; }
       }
 
       case B_AFTER_JAC: {
@@ -761,7 +763,7 @@ struct BcMachine {
         if (satisfied == nactive && (h.jte_inf <= c.o.eps1)) {
           h.dp_l2 = 0.0;
           h.stop = 1;
-          h.phase = B_FINISH;
+          ph = B_FINISH;
           break;
         }
         if (h.k == 0) {  // lmbc_core.c:666-674
@@ -773,7 +775,7 @@ struct BcMachine {
           } else
             h.mu = 0.5 * c.o.tau * h.p_e2;  // Kanzow's starting damping
         }
-        h.phase = B_SOLVE;
+        ph = B_SOLVE;
         break;
       }
 
@@ -786,7 +788,7 @@ struct BcMachine {
           const int nu2 = (int)((unsigned)h.nu << 1);
           if (nu2 <= h.nu) {
             h.stop = 5;
-            h.phase = B_END_ITER;
+            ph = B_END_ITER;
             break;
           }
           h.nu = nu2;
@@ -803,17 +805,17 @@ struct BcMachine {
         }
         if (h.dp_l2 <= c.o.eps2sq * h.p_l2) {
           h.stop = 2;
-          h.phase = B_END_ITER;
+          ph = B_END_ITER;
           break;
         }
         if (h.dp_l2 >= (h.p_l2 + c.o.eps2) / (kEpsilon * kEpsilon)) {
           h.stop = 4;
-          h.phase = B_END_ITER;
+          ph = B_END_ITER;
           break;
         }
         request_eval(c, h, h.pdp);
-        h.phase = B_AFTER_LM_EVAL;
-        return;
+        ph = B_AFTER_LM_EVAL;
+        { h.phase = ph; return; }
       }
 
       case B_AFTER_LM_EVAL:  // overflow guard, lmbc_core.c:748-751
@@ -821,26 +823,26 @@ struct BcMachine {
         if (!lm_finite(h.pdp_e2)) {
           if (!lm_finite(maxabs)) {
             h.stop = 7;
-            h.phase = B_END_ITER;
+            ph = B_END_ITER;
             break;
           }
           h.keep_max = maxabs;
           request_eval(c, h, h.pdp, RQ_SCALED);
           --h.nfev;  // not a user-visible function evaluation
           h.req.scal = maxabs;
-          h.phase = B_AFTER_LM_NORM;
-          return;
+          ph = B_AFTER_LM_NORM;
+          { h.phase = ph; return; }
         }
-        h.phase = B_LM_JUDGE;
+        ph = B_LM_JUDGE;
         break;
 
       case B_AFTER_LM_NORM:
         if (!lm_finite(h.keep_max * sqrt(s[0]))) {
           h.stop = 7;
-          h.phase = B_END_ITER;
+          ph = B_END_ITER;
           break;
         }
-        h.phase = B_LM_JUDGE;
+        ph = B_LM_JUDGE;
         break;
 
       case B_LM_JUDGE: {
@@ -859,7 +861,7 @@ struct BcMachine {
           h.nu = 2;
           accept_trial(h);
           h.gprev = 0;
-          h.phase = B_END_ITER;
+          ph = B_END_ITER;
           break;
         }
         h.gdp = 0.0;  // lmbc_core.c:811-816
@@ -868,7 +870,7 @@ struct BcMachine {
           h.gdp += h.jte[i] * h.dp[i];
         }
         if (!(h.gdp <= -rho * pow(h.dp_l2, kLsPow / 2.0))) {
-          h.phase = B_PG_BEGIN;
+          ph = B_PG_BEGIN;
           break;
         }
         // ---- line-search prologue, lmbc_core.c:227-249 (x = p, f = p_e2, g = jte, step = dp)
@@ -897,13 +899,13 @@ struct BcMachine {
         h.ls_first = 1;
         h.ls_plmbda = h.ls_pfpls = h.ls_tlmbda = 0.0;
         h.ls_left = kLsItMax;
-        h.phase = B_LS_ISSUE;
+        ph = B_LS_ISSUE;
         break;
       }
 
       case B_LS_ISSUE: {  // lmbc_core.c:253-266
         if (h.ls_left-- <= 0) {  // iteration limit: failure -> projected gradient
-          h.phase = B_PG_BEGIN;
+          ph = B_PG_BEGIN;
           break;
         }
         for (int i = M; i-- > 0;) h.pdp[i] = h.p[i] + h.ls_lambda * h.dp[i];
@@ -920,8 +922,8 @@ struct BcMachine {
           }
         }
         ++h.nfev;
-        h.phase = B_LS_EVAL;
-        return;
+        ph = B_LS_EVAL;
+        { h.phase = ph; return; }
       }
 
       case B_LS_EVAL: {  // lmbc_core.c:269-332
@@ -929,15 +931,15 @@ struct BcMachine {
         h.pdp_e2 = s[0];
         if (fpls <= h.ls_f0 + h.ls_slp * alpha * h.ls_lambda) {  // satisfactory point
           if (!lm_finite(h.pdp_e2)) {  // lmbc_core.c:828
-            h.phase = B_PG_BEGIN;
+            ph = B_PG_BEGIN;
             break;
           }
           h.gprev = 0;
-          h.phase = B_COMMIT;
+          ph = B_COMMIT;
           break;
         }
         if (h.ls_lambda < h.ls_rmnlmb) {
-          h.phase = B_PG_BEGIN;
+          ph = B_PG_BEGIN;
           break;
         }
         if (!lm_finite(fpls)) {
@@ -967,7 +969,7 @@ struct BcMachine {
           else
             h.ls_lambda = h.ls_tlmbda;
         }
-        h.phase = B_LS_ISSUE;
+        ph = B_LS_ISSUE;
         break;
       }
 
@@ -978,14 +980,14 @@ struct BcMachine {
         g2 = 100.0 / (1.0 + g2);
         h.t0 = (g2 <= tini) ? g2 : tini;
         h.t = h.gprev ? h.t : h.t0;
-        h.phase = B_PG_ISSUE;
+        ph = B_PG_ISSUE;
         break;
       }
 
       case B_PG_ISSUE: {  // loop head of lmbc_core.c:885
         if (!(h.t > tming)) {  // search failed, :937-939
           h.gprev = 0;
-          h.phase = B_END_ITER;
+          ph = B_END_ITER;
           break;
         }
         for (int i = 0; i < M; ++i) h.pdp[i] = h.p[i] - h.t * h.jte[i];
@@ -997,8 +999,8 @@ struct BcMachine {
           h.dp_l2 += d * d;
         }
         request_eval(c, h, h.pdp);
-        h.phase = B_PG_EVAL;
-        return;
+        ph = B_PG_EVAL;
+        { h.phase = ph; return; }
       }
 
       case B_PG_EVAL:
@@ -1006,26 +1008,26 @@ struct BcMachine {
         if (!lm_finite(h.pdp_e2)) {  // lmbc_core.c:915-918
           if (!lm_finite(maxabs)) {
             h.stop = 7;
-            h.phase = B_FINISH;
+            ph = B_FINISH;
             break;
           }
           h.keep_max = maxabs;
           request_eval(c, h, h.pdp, RQ_SCALED);
           --h.nfev;
           h.req.scal = maxabs;
-          h.phase = B_PG_NORM;
-          return;
+          ph = B_PG_NORM;
+          { h.phase = ph; return; }
         }
-        h.phase = B_PG_JUDGE;
+        ph = B_PG_JUDGE;
         break;
 
       case B_PG_NORM:
         if (!lm_finite(h.keep_max * sqrt(s[0]))) {
           h.stop = 7;
-          h.phase = B_FINISH;  // "goto breaknested": k is not advanced
+          ph = B_FINISH;  // "goto breaknested": k is not advanced
           break;
         }
-        h.phase = B_PG_JUDGE;
+        ph = B_PG_JUDGE;
         break;
 
       case B_PG_JUDGE: {  // lmbc_core.c:923-935
@@ -1035,16 +1037,16 @@ struct BcMachine {
           h.t = h.t0;
           h.gprev = 0;
           h.t *= beta;  // the reference's `continue` still runs the loop increment
-          h.phase = B_PG_ISSUE;
+          ph = B_PG_ISSUE;
           break;
         }
         if (h.pdp_e2 <= h.p_e2 + 2.0 * alpha * h.gdp) {
           h.gprev = 1;
-          h.phase = B_COMMIT;
+          ph = B_COMMIT;
           break;
         }
         h.t *= beta;
-        h.phase = B_PG_ISSUE;
+        ph = B_PG_ISSUE;
         break;
       }
 
@@ -1056,17 +1058,17 @@ struct BcMachine {
         }
         if (h.dp_l2 <= c.o.eps2sq * h.p_l2) {
           h.stop = 2;
-          h.phase = B_END_ITER;
+          ph = B_END_ITER;
           break;
         }
         accept_trial(h);
-        h.phase = B_END_ITER;
+        ph = B_END_ITER;
         break;
       }
 
       case B_END_ITER:
         ++h.k;
-        h.phase = B_ITER_TOP;
+        ph = B_ITER_TOP;
         break;
 
       case B_FINISH: {  // lmbc_core.c:973-1021, :1119-1124
@@ -1095,13 +1097,13 @@ struct BcMachine {
           for (int i = 0; i < M; ++i) h.p[i] *= c.dscl[i];
         c.ret = (h.stop != 4 && h.stop != 7) ? h.k : kLmError;
         clear_req(h);
-        h.phase = B_DONE;
-        return;
+        ph = B_DONE;
+        { h.phase = ph; return; }
       }
 
       default:
         h.req.kind = RQ_DONE;
-        return;
+        { h.phase = ph; return; }
       }
     }
   }

@@ -51,6 +51,9 @@ struct StreamCtx {
   long long t_first;
   long long n_jac, n_eval;
   long long stamps[8];
+#ifdef BRDF_STAMPS
+  int dbg[4096 * 4];  // diagnostic builds: per pass {step cycles, kind before*100+after, phase before*100+after}
+#endif
   MachineUnion m[2];  // double-buffered: pass k reads m[k&1], writes m[(k+1)&1]
 };
 

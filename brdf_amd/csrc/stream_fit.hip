@@ -111,7 +111,18 @@ __global__ __launch_bounds__(kStreamThreads, kStreamWavesPerSimd) void stream_pa
     default: block_reduce<1, kStreamThreads>(pv, pv[kSums], red, sums); break;
     }
     STAMP();
+#ifdef BRDF_STAMPS
+    const int kind_before_ = sm.h.req.kind, phase_before_ = sm.h.phase;
+    const long long ts0_ = clock64();
+#endif
     if (tid == 0) sm.step(sums, sums[kSums]);
+#ifdef BRDF_STAMPS
+    if (blockIdx.x == 0 && tid == 0 && pass < 4096) {
+      ctx->dbg[pass * 4 + 0] = (int)(clock64() - ts0_);
+      ctx->dbg[pass * 4 + 1] = kind_before_ * 100 + sm.h.req.kind;
+      ctx->dbg[pass * 4 + 2] = phase_before_ * 100 + sm.h.phase;
+    }
+#endif
     __syncthreads();
     STAMP();
   }
@@ -551,6 +562,17 @@ static int stream_fit_attempt(const StreamFitArgs &a, bool fast, bool *retry_exa
   ws.stats.eval_passes = mb.n_eval;
   ws.stats.device_us = (double)(mb.t_last - mb.t_first) / 100.0;  // s_memrealtime ticks at 100 MHz
   for (int k = 0; k < 8; ++k) ws.stats.stamps[k] = mb.stamps[k];
+#ifdef BRDF_STAMPS
+  if (const char *path = getenv("BRDF_HIP_STEP_DUMP")) {  // diagnostic: per-pass cost of the LM step by transition
+    static StreamCtx tmp;
+    (void)hipStreamSynchronize(a.stream);
+    (void)hipMemcpy(&tmp, ws.d_ctx, sizeof tmp, hipMemcpyDeviceToHost);
+    if (FILE *f = fopen(path, "a")) {
+      for (int i = 1; i < mb.passes && i < 4096; ++i) fprintf(f, "%d %d %d %d\n", a.method, tmp.dbg[i * 4], tmp.dbg[i * 4 + 1], tmp.dbg[i * 4 + 2]);
+      fclose(f);
+    }
+  }
+#endif
   return mb.ret;
 }
 
