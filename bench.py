@@ -76,10 +76,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # rehearsal knobs (not used by the driver): run N ranks on ONE GPU over gloo to exercise the N>1 code path
+    backend = os.environ.get("BRDF_BENCH_BACKEND", "nccl")
+    local = int(os.environ.get("BRDF_BENCH_DEVICE", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
 
     # each rank owns one material: same generator, different seed -> different planes and noise
     angles, x, truth = synth.make_single(MODEL, N_SAMPLES, seed=synth.SEED + 7919 * rank)
@@ -112,7 +119,7 @@ def main():
         ev1.record()
         gathered = None
         if world > 1:  # the one collective of the job: fitted parameters + info[] of every step -> rank 0
-            res_dev = results.to(dev)
+            res_dev = results.to(coll_dev)
             gathered = [torch.empty_like(res_dev) for _ in range(world)] if rank == 0 else None
             dist.gather(res_dev, gathered, dst=0)
             dist.barrier()
@@ -120,7 +127,7 @@ def main():
         wall = time.perf_counter() - t0
         ev_ms = ev0.elapsed_time(ev1)
         stat = torch.tensor([wall, float(results[:, 10].sum().item()) * N_SAMPLES, ev_ms, float(passes), float(jac), dev_us],
-                            dtype=torch.float64, device=dev)
+                            dtype=torch.float64, device=coll_dev)
         if world > 1:
             allstat = [torch.empty_like(stat) for _ in range(world)]
             dist.all_gather(allstat, stat)
@@ -153,6 +160,14 @@ def main():
         return
 
     head = out["dif"]
+    # HBM traffic per launch: measured with rocprofv3 PMC counters in separate profiling passes of this very
+    # command (scripts/profile_round.sh), corrected as MI355X_MICROARCH.md prescribes; committed under profiles/
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        traffic = tj["kernels"]["stream_pass<2, 0, true>"]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
     bytes_per_launch = BYTES_PER_SAMPLE_PASS[MODEL] * N_SAMPLES
     achieved = bytes_per_launch / (head["avg_launch_us"] * 1e-6) / 1e9
     line = {
@@ -165,12 +180,15 @@ def main():
                    "n_samples": N_SAMPLES, "model": "ward", "entry_point": "dlevmar_dif", "fits_per_step_per_gpu": 1,
                    "nfev_per_fit": head["nfev"], "lm_iterations": head["iters"], "passes_per_fit": head["passes_per_step"]},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None,
-                     "kernel": "brdf::stream_pass<2,0> (fused model eval + residual + Broyden + JtJ/Jte sweep, one launch per LM evaluation)",
+                     "traffic": traffic,
+                     "kernel": "brdf::stream_pass<2,0,true> (fused model eval + residual + Broyden + JtJ/Jte sweep, one launch per LM evaluation)",
                      "algorithmic_bytes_per_launch": bytes_per_launch,
                      "avg_launch_us": head["avg_launch_us"],
                      "note": "avg launch = HIP-event time of the timed region / pass launches in it (includes inter-launch gaps and the "
-                             "in-kernel LM state-machine step); 32 B per sample-pass for Ward (3 planes + measurement, fp64)"},
+                             "in-kernel LM state-machine step); 32 B per sample-pass for Ward (3 planes + measurement, fp64); traffic = "
+                             "HBM-side bytes per launch from rocprofv3 FETCH_SIZE (x2 gfx950 correction, calibrated) + WRITE_SIZE, "
+                             "profiles/r01_traffic.json: the dif trial pass really moves 96 B/sample (secant Jacobian and hx are "
+                             "read and rewritten), the bc_dif pass moves exactly the algorithmic 32 B/sample"},
         "fitted_params": head["p"], "sumsq": head["sumsq"],
         "bc_dif": {k: out["bc_dif"][k] for k in ("value", "ms_per_step", "nfev", "iters", "passes_per_step", "avg_launch_us", "p")},
     }

@@ -597,15 +597,23 @@ struct BcMachine {
   LM_HD static double median3(double a, double b, double c) {  // lmbc_core.c:59-61
     return (a >= b) ? ((c >= a) ? a : ((c <= b) ? b : c)) : ((c >= b) ? b : ((c <= a) ? a : c));
   }
+  // v must not alias the machine (callers pass a local array): the box is read once, up front -- on the
+  // device every dependent re-read of the LDS-resident machine costs a full LDS round trip
   static LM_HD void project(const Cold &c, double *v) {  // lmbc_core.c:68-88
-    if (!c.has_lb && !c.has_ub) return;
+    const int has_lb = c.has_lb, has_ub = c.has_ub;
+    if (!has_lb && !has_ub) return;
+    double lo[M], hi[M];
+    for (int i = 0; i < M; ++i) {
+      lo[i] = c.lb[i];
+      hi[i] = c.ub[i];
+    }
     for (int i = M; i-- > 0;) {
-      if (c.has_lb && c.has_ub)
-        v[i] = median3(c.lb[i], v[i], c.ub[i]);
-      else if (c.has_ub) {
-        if (v[i] > c.ub[i]) v[i] = c.ub[i];
+      if (has_lb && has_ub)
+        v[i] = median3(lo[i], v[i], hi[i]);
+      else if (has_ub) {
+        if (v[i] > hi[i]) v[i] = hi[i];
       } else {
-        if (v[i] < c.lb[i]) v[i] = c.lb[i];
+        if (v[i] < lo[i]) v[i] = lo[i];
       }
     }
   }
@@ -617,11 +625,16 @@ struct BcMachine {
     h.req.scal = 1.0;
     for (int i = 0; i < M; ++i) h.req.p[i] = h.req.d[i] = h.req.q[i] = h.req.dp[i] = 0.0;
   }
-  // ask for ||x - f(v)||^2 where v lives in the (possibly scaled) search space
+  // ask for ||x - f(v)||^2 where v lives in the (possibly scaled) search space.  Only the fields an
+  // evaluation pass reads are written (kind, p, scal); v is a local array.
   static LM_HD void request_eval(const Cold &c, Hot &h, const double *v, int kind = RQ_EVAL) {
-    clear_req(h);
     h.req.kind = kind;
-    for (int i = 0; i < M; ++i) h.req.p[i] = c.has_dscl ? v[i] * c.dscl[i] : v[i];
+    h.req.scal = 1.0;
+    if (c.has_dscl) {
+      for (int i = 0; i < M; ++i) h.req.p[i] = v[i] * c.dscl[i];
+    } else {
+      for (int i = 0; i < M; ++i) h.req.p[i] = v[i];
+    }
     ++h.nfev;
   }
 
@@ -795,25 +808,31 @@ struct BcMachine {
           for (int i = 0; i < M; ++i) h.jtj[i * M + i] = h.diag[i];
           break;  // solve again
         }
-        for (int i = 0; i < M; ++i) h.pdp[i] = h.p[i] + h.dp[i];
-        project(c, h.pdp);
-        h.dp_l2 = 0.0;
+        double pc[M], v[M], l2 = 0.0;
         for (int i = 0; i < M; ++i) {
-          const double d = h.pdp[i] - h.p[i];
-          h.dp[i] = d;
-          h.dp_l2 += d * d;
+          pc[i] = h.p[i];
+          v[i] = pc[i] + h.dp[i];
         }
-        if (h.dp_l2 <= c.o.eps2sq * h.p_l2) {
+        project(c, v);
+        for (int i = 0; i < M; ++i) {
+          const double d = v[i] - pc[i];
+          h.pdp[i] = v[i];
+          h.dp[i] = d;
+          l2 += d * d;
+        }
+        h.dp_l2 = l2;
+        const double pl2 = h.p_l2;
+        if (l2 <= c.o.eps2sq * pl2) {
           h.stop = 2;
           ph = B_END_ITER;
           break;
         }
-        if (h.dp_l2 >= (h.p_l2 + c.o.eps2) / (kEpsilon * kEpsilon)) {
+        if (l2 >= (pl2 + c.o.eps2) / (kEpsilon * kEpsilon)) {
           h.stop = 4;
           ph = B_END_ITER;
           break;
         }
-        request_eval(c, h, h.pdp);
+        request_eval(c, h, v);
         ph = B_AFTER_LM_EVAL;
         { h.phase = ph; return; }
       }
@@ -908,17 +927,23 @@ struct BcMachine {
           ph = B_PG_BEGIN;
           break;
         }
-        for (int i = M; i-- > 0;) h.pdp[i] = h.p[i] + h.ls_lambda * h.dp[i];
-        project(c, h.pdp);
-        clear_req(h);
+        double v[M];
+        const double lam = h.ls_lambda;
+        for (int i = M; i-- > 0;) v[i] = h.p[i] + lam * h.dp[i];
+        project(c, v);
         h.req.kind = RQ_EVAL;
+        h.req.scal = 1.0;
         if (!c.has_dscl) {
-          for (int i = 0; i < M; ++i) h.req.p[i] = h.pdp[i];
+          for (int i = 0; i < M; ++i) {
+            h.req.p[i] = v[i];
+            h.pdp[i] = v[i];
+          }
         } else {  // the reference multiplies and divides xpls in place, lmbc_core.c:263-265
           for (int i = M; i-- > 0;) {
-            h.pdp[i] *= c.dscl[i];
-            h.req.p[i] = h.pdp[i];
-            h.pdp[i] /= c.dscl[i];
+            v[i] *= c.dscl[i];
+            h.req.p[i] = v[i];
+            v[i] /= c.dscl[i];
+            h.pdp[i] = v[i];
           }
         }
         ++h.nfev;
@@ -990,15 +1015,21 @@ struct BcMachine {
           ph = B_END_ITER;
           break;
         }
-        for (int i = 0; i < M; ++i) h.pdp[i] = h.p[i] - h.t * h.jte[i];
-        project(c, h.pdp);
-        h.dp_l2 = 0.0;
+        const double tt = h.t;
+        double pc[M], v[M], l2 = 0.0;
         for (int i = 0; i < M; ++i) {
-          const double d = h.pdp[i] - h.p[i];
-          h.dp[i] = d;
-          h.dp_l2 += d * d;
+          pc[i] = h.p[i];
+          v[i] = pc[i] - tt * h.jte[i];
         }
-        request_eval(c, h, h.pdp);
+        project(c, v);
+        for (int i = 0; i < M; ++i) {
+          const double d = v[i] - pc[i];
+          h.pdp[i] = v[i];
+          h.dp[i] = d;
+          l2 += d * d;
+        }
+        h.dp_l2 = l2;
+        request_eval(c, h, v);
         ph = B_PG_EVAL;
         { h.phase = ph; return; }
       }
@@ -1012,7 +1043,9 @@ struct BcMachine {
             break;
           }
           h.keep_max = maxabs;
-          request_eval(c, h, h.pdp, RQ_SCALED);
+          double v[M];
+          for (int i = 0; i < M; ++i) v[i] = h.pdp[i];
+          request_eval(c, h, v, RQ_SCALED);
           --h.nfev;
           h.req.scal = maxabs;
           ph = B_PG_NORM;
@@ -1031,21 +1064,24 @@ struct BcMachine {
         break;
 
       case B_PG_JUDGE: {  // lmbc_core.c:923-935
-        h.gdp = 0.0;
-        for (int i = 0; i < M; ++i) h.gdp += h.jte[i] * h.dp[i];
-        if (h.gprev && h.pdp_e2 <= h.p_e2 + 2.0 * 0.99999 * h.gdp) {  // remembered t was too small
-          h.t = h.t0;
+        double g = 0.0;
+        for (int i = 0; i < M; ++i) g += h.jte[i] * h.dp[i];
+        h.gdp = g;
+        const double fnew = h.pdp_e2, fold = h.p_e2;
+        if (h.gprev && fnew <= fold + 2.0 * 0.99999 * g) {  // remembered t was too small
+          double tt = h.t0;
           h.gprev = 0;
-          h.t *= beta;  // the reference's `continue` still runs the loop increment
+          tt *= beta;  // the reference's `continue` still runs the loop increment
+          h.t = tt;
           ph = B_PG_ISSUE;
           break;
         }
-        if (h.pdp_e2 <= h.p_e2 + 2.0 * alpha * h.gdp) {
+        if (fnew <= fold + 2.0 * alpha * g) {
           h.gprev = 1;
           ph = B_COMMIT;
           break;
         }
-        h.t *= beta;
+        h.t = h.t * beta;
         ph = B_PG_ISSUE;
         break;
       }
