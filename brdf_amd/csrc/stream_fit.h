@@ -78,6 +78,10 @@ struct FitStats {
 };
 FitStats stream_fit_last_stats();
 
+// persistent single-launch variant (persist_fit.hip): true if it handled the fit
+bool persist_fit_try(const StreamFitArgs &a, int *ret);
+FitStats persist_fit_last_stats();
+
 bool brdf_fast_path_enabled();  // false when BRDF_HIP_EXACT_POW=1
 void set_error(const char *fmt, ...);
 const char *get_error();

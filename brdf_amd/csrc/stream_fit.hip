@@ -457,7 +457,8 @@ int blocks_for(int n) {
 
 }  // namespace
 
-FitStats stream_fit_last_stats() { return g_ws.stats; }
+static thread_local bool g_last_was_persistent = false;
+FitStats stream_fit_last_stats() { return g_last_was_persistent ? persist_fit_last_stats() : g_ws.stats; }
 bool brdf_fast_path_enabled();
 
 // one attempt on the FAST (prepared-sample) or the exact model path; *retry_exact is set when the FAST path
@@ -610,6 +611,15 @@ int stream_fit_run(const StreamFitArgs &a) {
 
   double p_keep[kM];
   for (int i = 0; i < kM; ++i) p_keep[i] = a.p[i];
+  {  // fits that fit the chip's register file run as ONE persistent launch (persist_fit.hip)
+    int pret = 0;
+    if (persist_fit_try(a, &pret)) {
+      g_last_was_persistent = true;
+      return pret;
+    }
+    for (int i = 0; i < kM; ++i) a.p[i] = p_keep[i];
+    g_last_was_persistent = false;
+  }
   bool retry = false;
   int ret = stream_fit_attempt(a, brdf_fast_path_enabled(), &retry);
   if (retry) {  // a cosine <= 0 on the cached-log path: redo with the reference's pow expression

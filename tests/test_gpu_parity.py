@@ -298,3 +298,43 @@ def test_device_generator_matches_host_generator(gpu):
     torch.cuda.synchronize()
     assert np.array_equal(a.cpu().numpy(), angles)  # planes: pure integer hashing + one fma -> identical bits
     assert np.max(np.abs(xd.cpu().numpy() - x)) <= 1e-15  # measurements: device exp vs numpy exp
+
+
+def test_persistent_single_launch_variant(gpu, monkeypatch):
+    """opt-in alternative of the streamed regime (persist_fit.hip): the whole fit in ONE launch, samples and the
+    secant Jacobian in registers, passes separated by a ticket/flag hand-off.  Same machines, same parity bar."""
+    monkeypatch.setenv("BRDF_HIP_PERSISTENT", "1")
+    for model, n in ((2, 100000), (1, 5000), (0, 300)):
+        angles, x, _ = synth.make_single(model, n)
+        for method in (0, 1):
+            _, p_ref, info_ref = L.brdf_fit("orc", method, model, angles, x, synth.P0[model], synth.ITMAX, synth.OPTS,
+                                            synth.LB, synth.UB)
+            _check(_dev_fit(gpu, method, model, angles, x), p_ref, info_ref)
+
+
+def test_diagonal_scaling_and_nan_input(gpu):
+    """dscl (lmbc_core.c:536-540, :555-569) and the stop-reason-7 path (non-finite function values ->
+    LM_ERROR, lm_core.c:562, :749; lmbc_core.c:534)"""
+    torch, brdf_amd, dev = gpu
+    model, n = 1, 4000
+    angles, x, _ = synth.make_single(model, n)
+    dscl = (1.0, 2.0, 50.0)
+    flat = np.ascontiguousarray(angles.reshape(-1))
+
+    class Extra(C.Structure):
+        _fields_ = [("angles", L.D), ("modelInfo", C.c_int)]
+
+    p = np.array(synth.P0[model])
+    info, opts = np.zeros(10), np.array(synth.OPTS)
+    lb, ub, ds = np.array(synth.LB), np.array(synth.UB), np.array(dscl)
+    fptr = C.cast(L.orc.orc_brdf_func, C.c_void_p)
+    r = L.orc.orc_dlevmar_bc_dif(fptr, L.ptr(p), L.ptr(x), 3, n, L.ptr(lb), L.ptr(ub), L.ptr(ds), synth.ITMAX, L.ptr(opts),
+                                 L.ptr(info), None, None, C.byref(Extra(L.ptr(flat), model)))
+    res = _dev_fit(gpu, 1, model, angles, x, dscl=dscl)
+    assert r >= 0
+    _check(res, p, info, p_tol=1e-4)
+    xb = x.copy()
+    xb[17] = np.nan
+    for method in (0, 1):
+        res = _dev_fit(gpu, method, model, angles, xb)
+        assert res.ret == -1 and res.info[6] == 7
