@@ -34,8 +34,16 @@ struct BatchCtx {
 template <int METHOD>
 using BatchMachine = typename std::conditional<METHOD == 0, DifMachine<kM>, BcMachine<kM>>::type;
 
+// Occupancy: the LM step between two passes runs on one lane (~3700 cycles on gfx950) while the rest of the
+// workgroup waits, so throughput comes from OTHER workgroups on the same CU filling that time.  Measured: asking
+// for 4 waves per SIMD (<= 128 VGPRs) pays for the one-sample-per-lane kernels (n <= 64: +20..50 % fits/s) but
+// makes the larger geometries spill their register-resident samples (n = 4096 bc_dif: 3x slower), so only the
+// smallest geometry is constrained.
+template <int THREADS, int SPT>
+constexpr int batch_waves_per_simd() { return (THREADS == 64 && SPT == 1) ? 4 : 2; }
+
 template <int MODEL, int METHOD, bool FAST, int THREADS, int SPT>
-__global__ __launch_bounds__(THREADS) void batch_fit_kernel(BatchCtx ctx) {
+__global__ __launch_bounds__(THREADS, (batch_waves_per_simd<THREADS, SPT>())) void batch_fit_kernel(BatchCtx ctx) {
   using Machine = BatchMachine<METHOD>;
   using Mdl = BrdfModel<MODEL>;
   __shared__ Machine sm;

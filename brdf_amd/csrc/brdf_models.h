@@ -133,7 +133,7 @@ struct PassUniforms {
   // only what the request kind reads is computed (each lin()/nl() hides an fp64 division or two, and on the
   // device this runs on a single lane between two passes)
   LM_HD void build(const Request<kM> &r) {
-    if (r.kind != RQ_DIF_TRIAL && r.kind != RQ_DIF_UPDATE) {
+    if (r.kind != RQ_DIF_UPDATE) {
       l0 = Mdl::lin(r.p);
       n0 = Mdl::nl(r.p);
     }

@@ -254,12 +254,12 @@ __global__ __launch_bounds__(kStreamThreads, kStreamWavesPerSimd) void stream_pa
     block_reduce<SumLayout<kM>::JAC, kStreamThreads>(acc, mx, red, sums);
     break;
   case RQ_DIF_INIT: {
-    double *__restrict__ hx = ctx->hx[sm.h.req.sel_hx];
+    // f(p) is never stored: wherever dlevmar_dif reads its hx vector (lm_core.c:580, :763, :785) the pass
+    // re-evaluates it from the same p with the same code -- identical bits, one exp instead of 16 B of traffic
     SWEEP_BEGIN(4)
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const double f = model_value<MODEL, FAST>(u, s0[k], pq[k]);
-      if (ok[k]) hx[idx[k]] = f;
       const double e = ok[k] ? sx[k] - f : 0.0;
       acc[0] += e * e;
     }
@@ -269,17 +269,13 @@ __global__ __launch_bounds__(kStreamThreads, kStreamWavesPerSimd) void stream_pa
     break;
   }
   case RQ_DIF_JAC: {
-    const double *__restrict__ hx = ctx->hx[sm.h.req.sel_hx];
     double *__restrict__ jb = ctx->jac[sm.h.req.sel_j];
     SWEEP_BEGIN(4)
-    double h[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) h[k] = hx[idx[k]];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       double f0 = 0.0, j[kM];
-      model_fd_row<MODEL, FAST>(u, s0[k], pq[k], false, f0, h[k], true, j);
-      double e = sx[k] - h[k];
+      model_fd_row<MODEL, FAST>(u, s0[k], pq[k], true, f0, 0.0, false, j);
+      double e = sx[k] - f0;
       if (ok[k]) {
         jb[idx[k]] = j[0];
         jb[(size_t)n + idx[k]] = j[1];
@@ -295,15 +291,12 @@ __global__ __launch_bounds__(kStreamThreads, kStreamWavesPerSimd) void stream_pa
     break;
   }
   case RQ_DIF_TRIAL: {
-    const double *__restrict__ hx = ctx->hx[sm.h.req.sel_hx];
-    double *__restrict__ hn = ctx->hx[sm.h.req.sel_hx ^ 1];
     const double *__restrict__ jo = ctx->jac[sm.h.req.sel_j];
     double *__restrict__ jn = ctx->jac[sm.h.req.sel_j ^ 1];
     SWEEP_BEGIN(4)
     double h[4], jold[4][kM];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      h[k] = hx[idx[k]];
       jold[k][0] = jo[idx[k]];
       jold[k][1] = jo[(size_t)n + idx[k]];
       jold[k][2] = jo[2 * (size_t)n + idx[k]];
@@ -311,11 +304,11 @@ __global__ __launch_bounds__(kStreamThreads, kStreamWavesPerSimd) void stream_pa
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const double w = model_value_q<MODEL, FAST>(u, s0[k], pq[k]);
+      h[k] = model_value<MODEL, FAST>(u, s0[k], pq[k]);  // f(p), see RQ_DIF_INIT
       double j[kM];
       broyden_row(jold[k], w, h[k], u.dp, u.dp_l2, j);
       double en = sx[k] - w, eo = sx[k] - h[k];
       if (ok[k]) {
-        hn[idx[k]] = w;
         jn[idx[k]] = j[0];
         jn[(size_t)n + idx[k]] = j[1];
         jn[2 * (size_t)n + idx[k]] = j[2];
