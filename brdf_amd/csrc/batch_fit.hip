@@ -9,6 +9,7 @@
 // sweep over the lane's SPT cached samples followed by a DPP/LDS workgroup reduction; the scalar LM
 // state machine (lm_machine.h) lives in LDS and is stepped by lane 0.  Fits finish after different
 // numbers of passes; the hardware workgroup scheduler backfills, which is the load balancing.
+#include <cstdlib>
 #include <cstring>
 #include <type_traits>
 
@@ -219,6 +220,185 @@ __global__ __launch_bounds__(THREADS, (batch_waves_per_simd<THREADS, SPT>())) vo
 }
 
 // ---------------------------------------------------------------------------------------------------
+// n <= 16 (the application's own size: 16 lights per surfel, brdfdata.h:58): FOUR fits per wavefront.
+// A fit owns one DPP row of 16 lanes (one sample per lane); its sums are reduced with four row_shr steps and
+// land in the row's last lane, which also owns the fit's LM machine (LDS) and steps it -- the four row leaders
+// step concurrently.  Rows pull fits from a global queue, so a row whose fit ends early starts the next one
+// while its neighbours are still iterating (fits take 10..100+ LM iterations each).
+// ---------------------------------------------------------------------------------------------------
+constexpr int kRowLanes = 16;
+constexpr int kRowsPerWave = kWave / kRowLanes;
+
+template <int MODEL, int METHOD, bool FAST>
+__global__ __launch_bounds__(kWave, 4) void batch_fit_rows_kernel(BatchCtx ctx, int *queue) {
+  using Machine = BatchMachine<METHOD>;
+  using Mdl = BrdfModel<MODEL>;
+  __shared__ Machine sm[kRowsPerWave];
+  __shared__ PassUniforms<MODEL> su[kRowsPerWave];
+  __shared__ int s_fit[kRowsPerWave];
+
+  const int lane = threadIdx.x;
+  const int row = lane / kRowLanes;
+  const int j = lane % kRowLanes;
+  const bool leader = (j == kRowLanes - 1);
+  const int n = ctx.n;
+  Machine &m = sm[row];
+  const PassUniforms<MODEL> &u = su[row];
+
+  bool row_live = true;  // false once the queue is empty for this row
+  while (__any(row_live)) {
+    // ---- fetch the next fit for every row that needs one ----------------------------------------------------
+    if (row_live && leader) {
+      int f;
+      for (;;) {
+        f = atomicAdd(queue, 1);
+        if (f >= ctx.S) {
+          f = -1;
+          break;
+        }
+        if (FAST || ctx.flags[f] == kNeedsExact) break;  // exact twin: only the fits the fast kernel declined
+      }
+      s_fit[row] = f;
+    }
+    __syncthreads();
+    const int fit = row_live ? s_fit[row] : -1;
+    if (fit < 0) row_live = false;
+
+    double s0 = 1.0, sx = 0.0, hx = 0.0, wrk = 0.0, jac[kM] = {0.0, 0.0, 0.0};
+    Prep pq{1.0, 1.0};
+    const bool ok = row_live && j < n;
+    bool declined = false;
+    if (row_live) {
+      const double *c0 = ctx.angles + (size_t)fit * 3 * n;
+      double r1 = 1.0, r2 = 1.0;
+      if (ok) {
+        s0 = c0[j];
+        r1 = Mdl::uses_c1 ? c0[n + j] : 0.0;
+        r2 = Mdl::uses_c2 ? c0[2 * (size_t)n + j] : 0.0;
+        sx = ctx.x[(size_t)fit * n + j];
+      }
+      pq = Mdl::template prepare<FAST>(s0, r1, r2);
+      if (FAST) {  // a cosine <= 0 anywhere in this fit (row-wide OR through the DPP max): leave it to the exact twin
+        const double bad = row_reduce_to_last<OpMax>((ok && !Mdl::domain_ok(s0, r1, r2)) ? 1.0 : 0.0);
+        if (leader) ctx.flags[fit] = (bad > 0.0) ? kNeedsExact : 0;
+        if (leader) s_fit[row] = (bad > 0.0) ? -2 : fit;
+      }
+    }
+    __syncthreads();
+    if (FAST && row_live && s_fit[row] == -2) declined = true;
+    const bool run = row_live && !declined;
+
+    if (run && leader) {
+      const double *p0 = ctx.p + (size_t)fit * kM;
+      const double *opts = ctx.has_opts ? ctx.opts : nullptr;
+      if constexpr (METHOD == 0)
+        m.start(p0, n, ctx.itmax, opts, 0, /*speculative=*/0);
+      else
+        m.start(p0, n, ctx.has_lb ? ctx.lb : nullptr, ctx.has_ub ? ctx.ub : nullptr, nullptr, ctx.itmax, opts, 0);
+    }
+    __syncthreads();
+
+    // ---- the fit: passes until this row's machine is done (rows are in different passes: divergent switch) --
+    bool busy = run;
+    while (__any(busy)) {
+      if (busy && leader) {
+        if (m.h.req.kind != RQ_DONE) su[row].build(m.h.req);
+      }
+      __syncthreads();
+      const int kind = busy ? m.h.req.kind : RQ_DONE;
+      if (kind == RQ_DONE) busy = false;
+      double acc[kSums];
+#pragma unroll
+      for (int k = 0; k < kSums; ++k) acc[k] = 0.0;
+      double mx = 0.0;
+      int ns = 0;
+      if (busy) {
+        switch (kind) {
+        case RQ_EVAL: {
+          const double e = ok ? sx - model_value<MODEL, FAST>(u, s0, pq) : 0.0;
+          acc[0] = e * e;
+          mx = fabs(e);
+          ns = 1;
+          break;
+        }
+        case RQ_SCALED: {
+          const double t = ok ? (sx - model_value<MODEL, FAST>(u, s0, pq)) / u.scal : 0.0;
+          acc[0] = t * t;
+          ns = 1;
+          break;
+        }
+        case RQ_JAC: {
+          double f0 = 0.0, jr[kM];
+          model_fd_row<MODEL, FAST>(u, s0, pq, true, f0, 0.0, false, jr);
+          double e = sx - f0;
+          if (!ok) e = jr[0] = jr[1] = jr[2] = 0.0;
+          acc_normal_eq(jr, e, acc, acc + kNL);
+          acc[kNL + kM] = e * e;
+          ns = SumLayout<kM>::JAC;
+          break;
+        }
+        case RQ_DIF_INIT: {
+          hx = model_value<MODEL, FAST>(u, s0, pq);
+          const double e = ok ? sx - hx : 0.0;
+          acc[0] = e * e;
+          ns = 1;
+          break;
+        }
+        case RQ_DIF_JAC: {
+          double f0 = 0.0;
+          model_fd_row<MODEL, FAST>(u, s0, pq, false, f0, hx, true, jac);
+          double e = sx - hx;
+          if (!ok) e = jac[0] = jac[1] = jac[2] = 0.0;
+          acc_normal_eq(jac, e, acc, acc + kNL);
+          ns = SumLayout<kM>::DIF_JAC;
+          break;
+        }
+        case RQ_DIF_TRIAL: {
+          wrk = model_value_q<MODEL, FAST>(u, s0, pq);
+          const double e = ok ? sx - wrk : 0.0;
+          acc[0] = e * e;
+          ns = 1;
+          break;
+        }
+        case RQ_DIF_UPDATE: {
+          const bool accepted = m.h.req.aux != 0;
+          double jn[kM];
+          broyden_row(jac, wrk, hx, u.dp, u.dp_l2, jn);
+          double e = sx - (accepted ? wrk : hx);
+          if (!ok) e = jn[0] = jn[1] = jn[2] = 0.0;
+          jac[0] = jn[0];
+          jac[1] = jn[1];
+          jac[2] = jn[2];
+          if (accepted) hx = wrk;
+          acc_normal_eq(jn, e, acc, acc + kNL);
+          ns = SumLayout<kM>::DIF_JAC;
+          break;
+        }
+        default: break;
+        }
+      }
+      // row reductions: DPP only (every lane takes part; idle rows reduce zeros)
+      double sums[kSlots];
+#pragma unroll
+      for (int k = 0; k < kSums; ++k) sums[k] = row_reduce_to_last<OpSum>(acc[k]);
+      sums[kSums] = row_reduce_to_last<OpMax>(mx);
+      (void)ns;
+      if (busy && leader) m.step(sums, sums[kSums]);
+      __syncthreads();
+    }
+
+    if (run && leader) {
+      double *po = ctx.p + (size_t)fit * kM;
+      for (int i = 0; i < kM; ++i) po[i] = m.h.p[i];
+      if (ctx.info)
+        for (int i = 0; i < kInfoSz; ++i) ctx.info[(size_t)fit * kInfoSz + i] = m.c.info[i];
+      if (ctx.ret) ctx.ret[fit] = m.c.ret;
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // synthetic sample generator (bench support): the counter stream of brdf_amd/synth.py on the device
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double synth_uniform(unsigned long long seed, unsigned long long index) {
@@ -311,6 +491,64 @@ thread_local FlagBuf g_flags;
     }                                                                                 \
   } while (0)
 
+namespace {
+
+using RowsFn = void (*)(BatchCtx, int *);
+RowsFn rows_kernel(int model, int method, bool fast) {
+  static const RowsFn table[2][MODEL_COUNT][2] = {
+      {{batch_fit_rows_kernel<0, 0, false>, batch_fit_rows_kernel<0, 1, false>},
+       {batch_fit_rows_kernel<1, 0, false>, batch_fit_rows_kernel<1, 1, false>},
+       {nullptr, nullptr}},
+      {{batch_fit_rows_kernel<0, 0, true>, batch_fit_rows_kernel<0, 1, true>},
+       {batch_fit_rows_kernel<1, 0, true>, batch_fit_rows_kernel<1, 1, true>},
+       {batch_fit_rows_kernel<2, 0, true>, batch_fit_rows_kernel<2, 1, true>}},
+  };
+  return table[fast ? 1 : 0][model][method];
+}
+
+bool rows_path_enabled() {  // BRDF_HIP_ROWS=0 selects the one-wave-per-fit kernel for n <= 16 as well
+  const char *e = getenv("BRDF_HIP_ROWS");
+  return !(e && e[0] == '0');
+}
+
+struct QueueBuf {
+  int *ptr = nullptr;
+  int device = -1;
+};
+thread_local QueueBuf g_queue;
+
+// four fits per wavefront, rows pull work from a queue: a few waves per SIMD on every CU are enough
+int rows_enqueue(const BatchFitArgs &a, const BatchCtx &c, bool fast) {
+  int dev = 0;
+  HIP_OK(hipGetDevice(&dev));
+  QueueBuf &q = g_queue;
+  if (q.device != dev || !q.ptr) {
+    HIP_OK(hipMalloc(&q.ptr, 2 * sizeof(int)));
+    q.device = dev;
+  }
+  hipDeviceProp_t prop;
+  HIP_OK(hipGetDeviceProperties(&prop, dev));
+  long long waves = (long long)prop.multiProcessorCount * 16;  // 4 waves per SIMD
+  const long long need = ((long long)a.S + kRowsPerWave - 1) / kRowsPerWave;
+  if (waves > need) waves = need;
+  HIP_OK(hipMemsetAsync(q.ptr, 0, 2 * sizeof(int), a.stream));
+  if (fast) {
+    hipLaunchKernelGGL(rows_kernel(a.model, a.method, true), dim3((unsigned)waves), dim3(kWave), 0, a.stream, c, q.ptr);
+    HIP_OK(hipGetLastError());
+    if (a.model != MODEL_WARD) {
+      hipLaunchKernelGGL(rows_kernel(a.model, a.method, false), dim3((unsigned)waves), dim3(kWave), 0, a.stream, c, q.ptr + 1);
+      HIP_OK(hipGetLastError());
+    }
+  } else {
+    HIP_OK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c.flags), kNeedsExact, (size_t)a.S, a.stream));
+    hipLaunchKernelGGL(rows_kernel(a.model, a.method, false), dim3((unsigned)waves), dim3(kWave), 0, a.stream, c, q.ptr);
+    HIP_OK(hipGetLastError());
+  }
+  return 0;
+}
+
+}  // namespace
+
 int batch_fit_enqueue(const BatchFitArgs &a) {
   if (a.model < 0 || a.model >= MODEL_COUNT || (a.method != 0 && a.method != 1)) {
     set_error("brdf_hip_fit_batch_dev(): unknown model %d / method %d", a.model, a.method);
@@ -370,6 +608,7 @@ int batch_fit_enqueue(const BatchFitArgs &a) {
       }
 
   const bool fast = brdf_fast_path_enabled() || a.model == MODEL_WARD;
+  if (a.n <= kRowLanes && rows_path_enabled()) return rows_enqueue(a, c, fast);
   const dim3 grid(a.S), block(g.threads);
   if (fast) {
     hipLaunchKernelGGL(kernel_for(g, a.model, a.method, true), grid, block, 0, a.stream, c);

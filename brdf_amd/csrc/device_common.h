@@ -45,6 +45,16 @@ __device__ __forceinline__ double wave_reduce_to_last(double v) {
   return v;
 }
 
+// reduction over one DPP row (16 lanes); result valid in the row's last lane (15, 31, 47, 63)
+template <class OP>
+__device__ __forceinline__ double row_reduce_to_last(double v) {
+  v = OP::apply(v, dpp_move<0x111, 0xf, 0xf>(v, OP::id()));  // row_shr:1
+  v = OP::apply(v, dpp_move<0x112, 0xf, 0xf>(v, OP::id()));  // row_shr:2
+  v = OP::apply(v, dpp_move<0x114, 0xf, 0xf>(v, OP::id()));  // row_shr:4
+  v = OP::apply(v, dpp_move<0x118, 0xf, 0xf>(v, OP::id()));  // row_shr:8
+  return v;
+}
+
 // Workgroup reduction of NS sums and one max.  The order is a pure function of (THREADS, NS): results are
 // reproducible run to run.  out[0..NS) receive the sums, out[kSums] the max; visible to all threads on return.
 //

@@ -41,7 +41,6 @@ struct Mailbox {
 struct StreamCtx {
   const double *c0, *c1, *c2, *x;
   double *prep[2]; // per-sample invariants written by pass 0 (FAST path): q1[n], q2[n]
-  double *hx[2];   // f(p) at the current / trial point          (dif only)
   double *jac[2];  // Jacobian, SoA: plane k at jac[b] + k*n     (dif only)
   double *partials;  // [2][kSlots][kStreamMaxBlocks]
   Mailbox *mbox;     // device-visible address of the pinned mailbox

@@ -6,9 +6,9 @@
 // one HBM/L2 sweep per LM evaluation.
 //
 // Data layout in HBM: the caller's SoA planes c0|c1|c2 (n doubles each) and x[n] are read in place,
-// 8 B per lane coalesced.  dif keeps two hx[n] buffers and two SoA Jacobians (3 planes of n) so the
-// trial pass can write the Broyden-updated Jacobian speculatively and the state machine commits by
-// flipping an index.  Workgroup b sweeps one contiguous tile; tiles are dealt so that the eight
+// 8 B per lane coalesced.  dif keeps two SoA secant Jacobians (3 planes of n each) so the trial pass can
+// write the Broyden-updated Jacobian speculatively and the state machine commits by flipping an index;
+// f(p) (levmar's hx vector) is re-evaluated where needed instead of being stored.  Workgroup b sweeps one contiguous tile; tiles are dealt so that the eight
 // workgroups {b, b+8, ...} that share an XCD own one contiguous eighth of the arrays, i.e. every
 // XCD's private L2 keeps seeing the same 1/8 slice on every pass.
 #include <chrono>
@@ -382,7 +382,7 @@ struct Workspace {
   Mailbox *h_mbox = nullptr;   // pinned + mapped
   Mailbox *d_mbox = nullptr;
   double *d_partials = nullptr;
-  double *d_dif = nullptr;  // per-sample scratch: 2n prepared planes + (dif) 2n hx + 6n two SoA Jacobians
+  double *d_dif = nullptr;  // per-sample scratch: 2n prepared planes + (dif) 6n = two SoA secant Jacobians
   size_t dif_cap = 0;
   hipStream_t last_stream = nullptr;
   bool used = false;
@@ -405,7 +405,7 @@ struct Workspace {
     if (d_dif) (void)hipFree(d_dif);
     d_dif = nullptr;
     dif_cap = 0;
-    HIP_OK(hipMalloc(&d_dif, sizeof(double) * 10 * n));
+    HIP_OK(hipMalloc(&d_dif, sizeof(double) * 8 * n));
     dif_cap = n;
     return 0;
   }
@@ -477,10 +477,8 @@ static int stream_fit_attempt(const StreamFitArgs &a, bool fast, bool *retry_exa
   if (ws.ensure_dif((size_t)a.n) != 0) return kLmError;
   h.prep[0] = ws.d_dif;
   h.prep[1] = ws.d_dif + (size_t)a.n;
-  h.hx[0] = ws.d_dif + 2 * (size_t)a.n;
-  h.hx[1] = ws.d_dif + 3 * (size_t)a.n;
-  h.jac[0] = ws.d_dif + 4 * (size_t)a.n;
-  h.jac[1] = ws.d_dif + 7 * (size_t)a.n;
+  h.jac[0] = ws.d_dif + 2 * (size_t)a.n;
+  h.jac[1] = ws.d_dif + 5 * (size_t)a.n;
 
   if (a.method == 0) {
     DifMachine<kM> &m = h.m[0].dif;
