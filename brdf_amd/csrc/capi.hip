@@ -12,6 +12,8 @@
 #include "stream_fit.h"
 
 namespace brdf {
+int generic_fit_run(int method, void (*func)(double *, double *, int, int, void *), double *p, double *x, int m, int n,
+                    double *lb, double *ub, double *dscl, int itmax, double *opts, double *info, double *covar, void *adata);
 int model_eval_run(int model, const double *d_angles, int n, const double *p, double *d_hx, hipStream_t stream);
 }
 
@@ -51,13 +53,12 @@ struct DevBuf {
 
 int host_fit(int method, const char *who, model_func_t func, double *p, double *x, int m, int n, double *lb,
              double *ub, double *dscl, int itmax, double *opts, double *info, double *covar, void *adata) {
-  if (!func || !is_registered(func)) {
-    set_error("%s(): `func` is not a registered BRDF model callback. A host function pointer cannot be "
-              "evaluated on the GPU: call brdf_hip_register_model(func) once (see INTEGRATION.md) or pass "
-              "BRDFFunc_hip",
-              who);
+  if (!func) {
+    set_error("%s(): func is NULL", who);
     return LM_ERROR;
   }
+  if (!is_registered(func))  // arbitrary host callback: evaluated on the host, all n-sized algebra on the device
+    return generic_fit_run(method, func, p, x, m, n, lb, ub, dscl, itmax, opts, info, covar, adata);
   if (m != kM) {
     set_error("%s(): the BRDF models have exactly 3 parameters (got m=%d)", who, m);
     return LM_ERROR;

@@ -1,0 +1,411 @@
+// generic_fit.hip -- dlevmar_dif / dlevmar_bc_dif for an ARBITRARY host callback (levmar.h:112-127).
+//
+// A host function pointer cannot run on the GPU, and it is the caller's code: it is evaluated on the host,
+// exactly when and where the reference would call it (same points, same order, same in-place perturbation
+// pattern is not needed because the callback only ever sees a private copy of p).  Everything n-sized the
+// reference does around those calls runs on the device:
+//   e = x - hx and ||e||^2                     misc_core.c:721-807   (K2)
+//   forward / central difference Jacobian fill   misc_core.c:153-171, :191-210   (K3)
+//   J^T J and J^T e                              lm_core.c:617-653, misc_core.c:82-134   (K4)
+//   Broyden rank-one update of J                 lm_core.c:760-766   (K5)
+// and the LM state machines of lm_machine.h (instantiated for the caller's m) sequence the passes from the
+// host, since every pass needs a host callback anyway.
+//
+// Summation order.  For problems with n*m <= 65536 the sums are formed by ONE lane in the reference's own
+// order (4-accumulator descending residual norm; descending "small problem" loop or 32-row blocked loop for
+// J^T J, with the reference's n*m <= 1024 / < 1024 switch): results are then bit-identical to levmar's, which
+// is what lets the reference's own known answers (lmdemo.c) be replayed through this ABI.
+// Larger problems use a deterministic workgroup tree (one workgroup; the callback dominates there anyway).
+#include <cstdio>
+#include <cstring>
+#include <type_traits>
+#include <vector>
+
+#include "stream_fit.h"
+
+namespace brdf {
+
+constexpr int kGenMaxM = 8;
+constexpr int kGenSums = kGenMaxM * (kGenMaxM + 1) / 2 + kGenMaxM + 2;  // JtJ lower + Jte + ||e||^2 + max
+constexpr int kGenThreads = 256;
+constexpr int kGenExactLimit = 65536;
+
+struct GenArgs {
+  const double *x;    // measurements (zeros if the caller passed NULL)
+  const double *hx;   // f(p)                       (device copy kept across passes for dif)
+  const double *aux;  // RQ_EVAL: f(point); RQ_JAC/RQ_DIF_JAC: hxx planes [j][n] (central: [2j] minus, [2j+1] plus)
+  double *wrk;        // dif: f(p + Dp) of the last trial
+  double *hx_rw;      // writable alias of hx (accept: hx <- wrk)
+  double *jac;        // n x m row-major, as levmar stores it (jac[i*m + j])
+  double *out;        // kGenSums doubles
+  int n, m, kind, central, exact, accepted, bc_rule, store_hx;
+  double dinv[kGenMaxM], dp[kGenMaxM], dp_l2, scal;
+};
+
+// ---- exact (reference-order) single-lane routines ---------------------------------------------------------
+__device__ double ref_l2(const double *x, const double *y, int n, double scal, bool scaled, double *mx_out) {
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  double mx = 0.0;
+  if (scaled) {  // lmbc_core.c:163-166, descending
+    double s = 0.0;
+    for (int i = n; i-- > 0;) {
+      const double t = (x[i] - y[i]) / scal;
+      s += t * t;
+    }
+    *mx_out = 0.0;
+    return s;
+  }
+  const int body = (n >> 3) << 3;  // misc_core.c:732-768
+  for (int top = body - 1; top > 0; top -= 8)
+    for (int k = 0; k < 8; ++k) {
+      const double e = x[top - k] - y[top - k];
+      acc[k & 3] += e * e;
+      mx = fmax(mx, fabs(e));
+    }
+  for (int t = body; t < n; ++t) {
+    const double e = x[t] - y[t];
+    acc[(7 - (n - t)) & 3] += e * e;
+    mx = fmax(mx, fabs(e));
+  }
+  *mx_out = mx;
+  return acc[0] + acc[1] + acc[2] + acc[3];
+}
+
+__device__ void ref_jtj_jte(const double *jac, const double *x, const double *h, int n, int m, bool small, double *jtj /*m*m*/,
+                            double *jte) {
+  if (small) {  // lm_core.c:617-637 / lmbc_core.c:595-615
+    for (int i = m * m; i-- > 0;) jtj[i] = 0.0;
+    for (int i = m; i-- > 0;) jte[i] = 0.0;
+    for (int l = n; l-- > 0;) {
+      const double *row = jac + (size_t)l * m;
+      const double el = x[l] - h[l];
+      for (int i = m; i-- > 0;) {
+        const double alpha = row[i];
+        for (int j = i + 1; j-- > 0;) jtj[i * m + j] += row[j] * alpha;
+        jte[i] += alpha * el;
+      }
+    }
+  } else {  // misc_core.c:103-128 (32-row blocks, upper triangle) + lm_core.c:645-653
+    for (int i = 0; i < m; ++i)
+      for (int j = i; j < m; ++j) jtj[i * m + j] = 0.0;
+    for (int kk = 0; kk < n; kk += 32) {
+      const int kend = (kk + 32 <= n) ? kk + 32 : n;
+      for (int i = 0; i < m; ++i)
+        for (int j = i; j < m; ++j) {
+          double s = 0.0;
+          for (int k = kk; k < kend; ++k) s += jac[(size_t)k * m + i] * jac[(size_t)k * m + j];
+          jtj[i * m + j] += s;
+        }
+    }
+    for (int i = 0; i < m; ++i)
+      for (int j = 0; j < i; ++j) jtj[i * m + j] = jtj[j * m + i];
+    for (int i = 0; i < m; ++i) jte[i] = 0.0;
+    for (int i = 0; i < n; ++i) {
+      const double ei = x[i] - h[i];
+      for (int l = 0; l < m; ++l) jte[l] += jac[(size_t)i * m + l] * ei;
+    }
+  }
+}
+
+__device__ void pack_sums(const double *jtj, const double *jte, int m, double *out) {
+  int c = 0;
+  for (int i = 0; i < m; ++i)
+    for (int j = 0; j <= i; ++j) out[c++] = jtj[i * m + j];
+  for (int i = 0; i < m; ++i) out[c++] = jte[i];
+}
+
+__global__ __launch_bounds__(kGenThreads) void gen_pass_kernel(GenArgs a) {
+  __shared__ double part[kGenThreads];
+  __shared__ double sh_out[kGenSums];
+  const int tid = threadIdx.x;
+  const int n = a.n, m = a.m;
+  const int nl = m * (m + 1) / 2;
+
+  // ---- element-wise stages, all lanes -------------------------------------------------------------------------
+  if (a.kind == RQ_DIF_INIT || (a.kind == RQ_EVAL && a.store_hx)) {
+    for (int i = tid; i < n; i += kGenThreads) a.hx_rw[i] = a.aux[i];
+  } else if (a.kind == RQ_DIF_TRIAL) {
+    for (int i = tid; i < n; i += kGenThreads) a.wrk[i] = a.aux[i];
+  } else if (a.kind == RQ_JAC || a.kind == RQ_DIF_JAC) {  // misc_core.c:167-170 / :206-209
+    for (int i = tid; i < n; i += kGenThreads)
+      for (int j = 0; j < m; ++j) {
+        const double v = a.central ? (a.aux[(size_t)(2 * j + 1) * n + i] - a.aux[(size_t)(2 * j) * n + i])
+                                   : (a.aux[(size_t)j * n + i] - a.hx[i]);
+        a.jac[(size_t)i * m + j] = v * a.dinv[j];
+      }
+  } else if (a.kind == RQ_DIF_UPDATE) {  // lm_core.c:760-766
+    for (int i = tid; i < n; i += kGenThreads) {
+      double *row = a.jac + (size_t)i * m;
+      double t = 0.0;
+      for (int l = 0; l < m; ++l) t += row[l] * a.dp[l];
+      t = (a.wrk[i] - a.hx[i] - t) / a.dp_l2;
+      for (int j = 0; j < m; ++j) row[j] += t * a.dp[j];
+    }
+  }
+  __syncthreads();
+
+  const double *y = (a.kind == RQ_EVAL || a.kind == RQ_SCALED) ? a.aux : ((a.kind == RQ_DIF_TRIAL) ? a.wrk : a.hx);
+  const double *h_for_e = (a.kind == RQ_DIF_UPDATE && a.accepted) ? a.wrk : a.hx;  // residual paired with J^T e
+  const bool wants_norm = (a.kind == RQ_EVAL || a.kind == RQ_SCALED || a.kind == RQ_DIF_INIT || a.kind == RQ_DIF_TRIAL || a.kind == RQ_JAC);
+  const bool wants_jtj = (a.kind == RQ_JAC || a.kind == RQ_DIF_JAC || a.kind == RQ_DIF_UPDATE);
+
+  if (a.exact) {
+    if (tid == 0) {
+      double mx = 0.0;
+      if (wants_jtj) {
+        double jtj[kGenMaxM * kGenMaxM], jte[kGenMaxM];
+        const int nm = n * m;
+        const bool small = a.bc_rule ? (nm < 1024) : (nm <= 1024);
+        ref_jtj_jte(a.jac, a.x, h_for_e, n, m, small, jtj, jte);
+        pack_sums(jtj, jte, m, sh_out);
+        if (a.kind == RQ_JAC) sh_out[nl + m] = ref_l2(a.x, a.hx, n, 1.0, false, &mx);
+      } else if (wants_norm) {
+        sh_out[0] = ref_l2(a.x, y, n, a.scal, a.kind == RQ_SCALED, &mx);
+      }
+      sh_out[kGenSums - 1] = mx;
+    }
+    __syncthreads();
+  } else {
+    // deterministic tree: strided per-lane accumulation, then a fixed LDS fold per sum
+    const int nsum = wants_jtj ? (nl + m + (a.kind == RQ_JAC ? 1 : 0)) : 1;
+    double acc[kGenSums];
+    for (int k = 0; k < kGenSums; ++k) acc[k] = 0.0;
+    double mx = 0.0;
+    for (int i = tid; i < n; i += kGenThreads) {
+      if (wants_jtj) {
+        const double *row = a.jac + (size_t)i * m;
+        const double e = a.x[i] - h_for_e[i];
+        int c = 0;
+        for (int r = 0; r < m; ++r)
+          for (int j = 0; j <= r; ++j) acc[c++] += row[r] * row[j];
+        for (int r = 0; r < m; ++r) acc[c++] += row[r] * e;
+        if (a.kind == RQ_JAC) {
+          const double e0 = a.x[i] - a.hx[i];
+          acc[c] += e0 * e0;
+        }
+      } else {
+        double e = a.x[i] - y[i];
+        if (a.kind == RQ_SCALED) e /= a.scal;
+        acc[0] += e * e;
+        mx = fmax(mx, fabs(e));
+      }
+    }
+    for (int k = 0; k <= nsum; ++k) {
+      part[tid] = (k < nsum) ? acc[k] : mx;
+      __syncthreads();
+      if (tid == 0) {
+        double s = part[0];
+        if (k < nsum)
+          for (int t = 1; t < kGenThreads; ++t) s += part[t];
+        else
+          for (int t = 1; t < kGenThreads; ++t) s = fmax(s, part[t]);
+        sh_out[(k < nsum) ? k : kGenSums - 1] = s;
+      }
+      __syncthreads();
+    }
+  }
+  if (a.kind == RQ_DIF_UPDATE && a.accepted) {  // e, hx <- trial values (lm_core.c:783-786)
+    for (int i = tid; i < n; i += kGenThreads) a.hx_rw[i] = a.wrk[i];
+  }
+  if (tid < kGenSums) a.out[tid] = sh_out[tid];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+#define HIP_OK(call)                                                                  \
+  do {                                                                                \
+    hipError_t e_ = (call);                                                           \
+    if (e_ != hipSuccess) {                                                           \
+      set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return kLmError;                                                                \
+    }                                                                                 \
+  } while (0)
+
+typedef void (*user_func_t)(double *p, double *hx, int m, int n, void *adata);
+
+namespace {
+
+struct GenBuffers {
+  double *d = nullptr;
+  size_t cap = 0;
+  ~GenBuffers() {
+    if (d) (void)hipFree(d);
+  }
+};
+
+template <int M, int METHOD>
+int generic_run(user_func_t func, double *p, double *x, int n, double *lb, double *ub, double *dscl, int itmax,
+                double *opts, double *info, double *covar, void *adata) {
+  using Machine = typename std::conditional<METHOD == 0, DifMachine<M>, BcMachine<M>>::type;
+  Machine mach;
+  if constexpr (METHOD == 0)
+    mach.start(p, n, itmax, opts, covar != nullptr, /*speculative=*/0);
+  else
+    mach.start(p, n, lb, ub, dscl, itmax, opts, covar != nullptr);
+  if (mach.h.req.kind == RQ_DONE) {
+    if constexpr (METHOD == 1) {
+      if (mach.c.bad_input == 2) {
+        set_error("dlevmar_bc_dif(): at least one lower bound exceeds the upper one");
+        return kLmError;
+      }
+      if (mach.c.bad_input == 3) {
+        set_error("dlevmar_bc_dif(): scaling constants should be positive");
+        return kLmError;
+      }
+    }
+    set_error("%s(): cannot solve a problem with fewer measurements [%d] than unknowns [%d]",
+              METHOD == 0 ? "dlevmar_dif" : "dlevmar_bc_dif", n, M);
+    return kLmError;
+  }
+  if constexpr (METHOD == 1)
+    for (int i = 0; i < M; ++i)
+      if (mach.c.infeasible_mask & (1 << i))
+        fprintf(stderr, "Warning: component %d of starting point not feasible in dlevmar_bc_dif()! [%g projected to %g]\n", i,
+                mach.c.p_start[i], mach.h.p[i]);
+
+  // device buffers: x | hx | wrk | aux (2M planes) | jac (n*M) | out
+  const size_t need = (size_t)n * (3 + 2 * M + M) + kGenSums;
+  GenBuffers buf;
+  HIP_OK(hipMalloc(&buf.d, need * sizeof(double)));
+  double *d_x = buf.d, *d_hx = d_x + n, *d_wrk = d_hx + n, *d_aux = d_wrk + n, *d_jac = d_aux + (size_t)2 * M * n,
+         *d_out = d_jac + (size_t)n * M;
+  std::vector<double> host_aux((size_t)2 * M * n);
+  if (x) {
+    HIP_OK(hipMemcpy(d_x, x, sizeof(double) * n, hipMemcpyHostToDevice));
+  } else {  // "NULL implies a zero vector", lm_core.c:441
+    HIP_OK(hipMemset(d_x, 0, sizeof(double) * n));
+  }
+  double sums_host[kGenSums];
+  double sums[SumLayout<M>::MAX + 2];
+  const bool exact = (long long)n * M <= kGenExactLimit;
+
+  long long guard = 0;
+  const long long cap = (long long)(itmax > 0 ? itmax : 1) * 700 + 64;
+  while (mach.h.req.kind != RQ_DONE) {
+    if (++guard > cap) {
+      set_error("pass budget exhausted without termination");
+      return kLmError;
+    }
+    const Request<M> &r = mach.h.req;
+    GenArgs a;
+    memset(&a, 0, sizeof a);
+    a.x = d_x;
+    a.hx = d_hx;
+    a.hx_rw = d_hx;
+    a.aux = d_aux;
+    a.wrk = d_wrk;
+    a.jac = d_jac;
+    a.out = d_out;
+    a.n = n;
+    a.m = M;
+    a.kind = r.kind;
+    a.central = r.central;
+    a.exact = exact ? 1 : 0;
+    a.accepted = r.aux;
+    a.bc_rule = METHOD;
+    a.scal = r.scal;
+    a.dp_l2 = r.dp_l2;
+    for (int j = 0; j < M; ++j) a.dp[j] = r.dp[j];
+    double pt[M];
+    size_t planes = 0;
+    switch (r.kind) {
+    case RQ_EVAL:
+    case RQ_SCALED:
+    case RQ_DIF_INIT:
+      for (int j = 0; j < M; ++j) pt[j] = r.p[j];
+      func(pt, host_aux.data(), M, n, adata);
+      planes = 1;
+      break;
+    case RQ_DIF_TRIAL:
+      for (int j = 0; j < M; ++j) pt[j] = r.q[j];
+      func(pt, host_aux.data(), M, n, adata);
+      planes = 1;
+      break;
+    case RQ_JAC:  // bc_dif re-evaluates f(p) on every Jacobian (lmbc_core.c:1049); forward only
+      if (!r.central) {
+        for (int j = 0; j < M; ++j) pt[j] = r.p[j];
+        func(pt, host_aux.data() + (size_t)M * n, M, n, adata);  // parked behind the M difference planes
+        HIP_OK(hipMemcpy(d_hx, host_aux.data() + (size_t)M * n, sizeof(double) * n, hipMemcpyHostToDevice));
+      }
+      [[fallthrough]];
+    case RQ_DIF_JAC:
+      for (int j = 0; j < M; ++j) {
+        a.dinv[j] = (r.central ? 0.5 : 1.0) / r.d[j];
+        for (int k = 0; k < M; ++k) pt[k] = r.p[k];
+        if (!r.central) {
+          pt[j] = r.p[j] + r.d[j];
+          func(pt, host_aux.data() + (size_t)j * n, M, n, adata);
+        } else {
+          pt[j] = r.p[j] - r.d[j];
+          func(pt, host_aux.data() + (size_t)(2 * j) * n, M, n, adata);
+          pt[j] = r.p[j] + r.d[j];
+          func(pt, host_aux.data() + (size_t)(2 * j + 1) * n, M, n, adata);
+        }
+      }
+      planes = r.central ? 2 * M : M;
+      break;
+    default: break;  // RQ_DIF_UPDATE: no evaluation
+    }
+    if (planes) HIP_OK(hipMemcpy(d_aux, host_aux.data(), sizeof(double) * planes * n, hipMemcpyHostToDevice));
+    // (bc with central differences never evaluates f(p): the residual paired with J^T e is the one of the last
+    // accepted point, which the device keeps in hx -- refreshed below whenever an evaluation is accepted)
+    a.store_hx = 0;
+    hipLaunchKernelGGL(gen_pass_kernel, dim3(1), dim3(kGenThreads), 0, 0, a);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipMemcpy(sums_host, d_out, sizeof(double) * kGenSums, hipMemcpyDeviceToHost));
+    const int ns = (r.kind == RQ_JAC) ? SumLayout<M>::JAC : ((r.kind == RQ_DIF_JAC || r.kind == RQ_DIF_UPDATE) ? SumLayout<M>::DIF_JAC : 1);
+    for (int k = 0; k < ns; ++k) sums[k] = sums_host[k];
+    const int kind_done = r.kind;
+    mach.step(sums, sums_host[kGenSums - 1]);
+    if constexpr (METHOD == 1) if (kind_done == RQ_EVAL) {
+      // bc keeps e of the last ACCEPTED point for central-difference Jacobians: mirror "e <- hx" (lmbc_core.c:779,
+      // :964) by keeping f(accepted point) on the device.  The machine accepted iff its p now equals the point
+      // that was just evaluated.
+      bool same = true;
+      for (int j = 0; j < M; ++j) {
+        const double cur = mach.c.has_dscl ? mach.h.p[j] * mach.c.dscl[j] : mach.h.p[j];
+        if (cur != pt[j]) same = false;
+      }
+      if (same) HIP_OK(hipMemcpy(d_hx, d_aux, sizeof(double) * n, hipMemcpyDeviceToDevice));
+    }
+  }
+  for (int i = 0; i < M; ++i) p[i] = mach.h.p[i];
+  if (info)
+    for (int i = 0; i < kInfoSz; ++i) info[i] = mach.c.info[i];
+  if (covar)
+    for (int i = 0; i < M * M; ++i) covar[i] = mach.c.covar[i];
+  return mach.c.ret;
+}
+
+template <int METHOD>
+int generic_dispatch(user_func_t func, double *p, double *x, int m, int n, double *lb, double *ub, double *dscl, int itmax,
+                     double *opts, double *info, double *covar, void *adata) {
+  switch (m) {
+  case 1: return generic_run<1, METHOD>(func, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
+  case 2: return generic_run<2, METHOD>(func, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
+  case 3: return generic_run<3, METHOD>(func, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
+  case 4: return generic_run<4, METHOD>(func, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
+  case 5: return generic_run<5, METHOD>(func, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
+  case 6: return generic_run<6, METHOD>(func, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
+  case 7: return generic_run<7, METHOD>(func, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
+  case 8: return generic_run<8, METHOD>(func, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
+  }
+  set_error("generic callback path supports 1 <= m <= %d parameters (got %d)", kGenMaxM, m);
+  return kLmError;
+}
+
+}  // namespace
+
+int generic_fit_run(int method, user_func_t func, double *p, double *x, int m, int n, double *lb, double *ub, double *dscl,
+                    int itmax, double *opts, double *info, double *covar, void *adata) {
+  if (!func || !p || n <= 0) {
+    set_error("generic fit: null callback / parameter vector or n <= 0");
+    return kLmError;
+  }
+  (void)hipGetLastError();
+  if (method == 0) return generic_dispatch<0>(func, p, x, m, n, lb, ub, dscl, itmax, opts, info, covar, adata);
+  return generic_dispatch<1>(func, p, x, m, n, lb, ub, dscl, itmax, opts, info, covar, adata);
+}
+
+}  // namespace brdf

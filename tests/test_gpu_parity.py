@@ -338,3 +338,78 @@ def test_diagonal_scaling_and_nan_input(gpu):
     for method in (0, 1):
         res = _dev_fit(gpu, method, model, angles, xb)
         assert res.ret == -1 and res.info[6] == 7
+
+
+# ---- arbitrary host callbacks: the reference's own known answers through the product ABI -------------------
+def _product_kat(lib, pr):
+    """run one lmdemo problem through libbrdf_hip's dlevmar_dif / dlevmar_bc_dif with the problem function taken,
+    by address, from the compiled reference object (a plain host callback the library knows nothing about)"""
+    from tests.kat_problems import OPTS
+    fp = C.cast(getattr(L.ref, pr["f"]), C.c_void_p)
+    p = L.f64(pr["p"]).copy()
+    x = L.f64(pr["x"])
+    m, n = p.size, x.size
+    info, opts = np.zeros(10), L.f64(OPTS)
+    covar = np.zeros(m * m) if pr.get("covar") else None
+    if pr["kind"] == "dif":
+        r = lib.dlevmar_dif(fp, L.ptr(p), L.ptr(x), m, n, pr["itmax"], L.ptr(opts), L.ptr(info), None, L.ptr(covar), None)
+    else:
+        lb, ub = L.f64(pr["lb"]), L.f64(pr["ub"])
+        r = lib.dlevmar_bc_dif(fp, L.ptr(p), L.ptr(x), m, n, L.ptr(lb), L.ptr(ub), None, pr["itmax"], L.ptr(opts),
+                               L.ptr(info), None, L.ptr(covar), None)
+    return r, p, info, covar
+
+
+@pytest.mark.skipif(L.ref is None, reason="lmdemo problem functions live in oracle/_ref")
+def test_lmdemo_known_answers_through_the_product_abi(gpu, capfd):
+    """generic_fit.hip: host callback evaluated on the host, residuals / FD Jacobian fill / J^T J / J^T e / Broyden on
+    the device in the reference's summation order (small problems) -> the reference's known answers replay BIT FOR
+    BIT through dlevmar_dif / dlevmar_bc_dif of libbrdf_hip.so: Wood, Meyer (with covariance), and the five
+    box-constrained problems through the finite-difference entry point."""
+    torch, brdf_amd, dev = gpu
+    from brdf_amd._lib import lib
+    from tests.kat_problems import PROBLEMS
+    gold = json.load(open(os.path.join(HERE, "golden", "lmdemo_kat.json")))["kats"]
+    ran = 0
+    for kat in gold:
+        if kat["entry"] not in ("dif", "bc_dif"):
+            continue
+        r, p, info, covar = _product_kat(lib, PROBLEMS[kat["problem"]])
+        hexs = lambda v: np.array([float.fromhex(s) for s in v])  # noqa: E731
+        assert r == kat["ret"], (kat["name"], r, kat["ret"])
+        assert np.array_equal(p, hexs(kat["p"])), (kat["name"], p)
+        assert np.array_equal(info, hexs(kat["info"])), (kat["name"], info)
+        if kat["covar"] is not None:
+            assert np.array_equal(covar, hexs(kat["covar"]))
+        ran += 1
+    assert ran == 7
+    capfd.readouterr()
+
+
+def test_unregistered_brdf_callback_takes_the_generic_path(gpu):
+    """an application callback that was NOT registered still works (it is called on the host); large n uses the
+    deterministic tree, so parity is to tolerance"""
+    torch, brdf_amd, dev = gpu
+    from brdf_amd._lib import D, ExtraData, MODEL_FUNC, lib
+    model, n = 1, 30000  # n*m > 65536: tree sums
+    angles, x, _ = synth.make_single(model, n)
+    flat = np.ascontiguousarray(angles.reshape(-1))
+    calls = []
+
+    @MODEL_FUNC
+    def app_func(p_, hx_, m_, n_, adata_):
+        calls.append(1)
+        pp = np.ctypeslib.as_array(p_, shape=(3,))
+        out = np.ctypeslib.as_array(hx_, shape=(n_,))
+        out[:] = pp[0] * angles[0] + pp[1] * np.power(angles[1], pp[2])
+
+    p = np.array(synth.P0[model])
+    info = np.zeros(10)
+    lb, ub, opts = np.array(synth.LB), np.array(synth.UB), np.array(synth.OPTS)
+    ed = ExtraData(flat.ctypes.data_as(D), model)
+    rc = lib.dlevmar_bc_dif(C.cast(app_func, C.c_void_p), p.ctypes.data_as(D), x.ctypes.data_as(D), 3, n,
+                            lb.ctypes.data_as(D), ub.ctypes.data_as(D), None, synth.ITMAX, opts.ctypes.data_as(D),
+                            info.ctypes.data_as(D), None, None, C.byref(ed))
+    _, p_ref, info_ref = L.brdf_fit("orc", 1, model, angles, x, synth.P0[model], synth.ITMAX, synth.OPTS, synth.LB, synth.UB)
+    assert rc >= 0 and len(calls) == info[7]
+    assert L.rel_err(p, p_ref) <= 1e-6 and abs(info[1] - info_ref[1]) <= 1e-9 * info_ref[1]
