@@ -12,8 +12,9 @@
 #include "stream_fit.h"
 
 namespace brdf {
-int generic_fit_run(int method, void (*func)(double *, double *, int, int, void *), double *p, double *x, int m, int n,
-                    double *lb, double *ub, double *dscl, int itmax, double *opts, double *info, double *covar, void *adata);
+int generic_fit_run(int method, void (*func)(double *, double *, int, int, void *),
+                    void (*jacf)(double *, double *, int, int, void *), double *p, double *x, int m, int n, double *lb,
+                    double *ub, double *dscl, int itmax, double *opts, double *info, double *covar, void *adata);
 int model_eval_run(int model, const double *d_angles, int n, const double *p, double *d_hx, hipStream_t stream);
 }
 
@@ -58,7 +59,7 @@ int host_fit(int method, const char *who, model_func_t func, double *p, double *
     return LM_ERROR;
   }
   if (!is_registered(func))  // arbitrary host callback: evaluated on the host, all n-sized algebra on the device
-    return generic_fit_run(method, func, p, x, m, n, lb, ub, dscl, itmax, opts, info, covar, adata);
+    return generic_fit_run(method, func, nullptr, p, x, m, n, lb, ub, dscl, itmax, opts, info, covar, adata);
   if (m != kM) {
     set_error("%s(): the BRDF models have exactly 3 parameters (got m=%d)", who, m);
     return LM_ERROR;
@@ -135,6 +136,21 @@ int dlevmar_bc_dif(void (*func)(double *, double *, int, int, void *), double *p
                    double *covar, void *adata) {
   return host_fit(BRDF_METHOD_BC_DIF, "dlevmar_bc_dif", func, p, x, m, n, lb, ub, dscl, itmax, opts, info, covar,
                   adata);
+}
+
+int dlevmar_bc_der(void (*func)(double *, double *, int, int, void *), void (*jacf)(double *, double *, int, int, void *),
+                   double *p, double *x, int m, int n, double *lb, double *ub, double *dscl, int itmax, double *opts,
+                   double *info, double * /*work*/, double *covar, void *adata) {
+  if (!func) {
+    set_error("dlevmar_bc_der(): func is NULL");
+    return LM_ERROR;
+  }
+  if (!jacf) {  // lmbc_core.c:445-449
+    set_error("No function specified for computing the Jacobian in dlevmar_bc_der(). If no such function is available, "
+              "use dlevmar_bc_dif() rather than dlevmar_bc_der()");
+    return LM_ERROR;
+  }
+  return generic_fit_run(BRDF_METHOD_BC_DIF, func, jacf, p, x, m, n, lb, ub, dscl, itmax, opts, info, covar, adata);
 }
 
 int brdf_hip_register_model(void (*func)(double *, double *, int, int, void *)) {

@@ -38,7 +38,7 @@ struct GenArgs {
   double *hx_rw;      // writable alias of hx (accept: hx <- wrk)
   double *jac;        // n x m row-major, as levmar stores it (jac[i*m + j])
   double *out;        // kGenSums doubles
-  int n, m, kind, central, exact, accepted, bc_rule, store_hx;
+  int n, m, kind, central, exact, accepted, bc_rule, store_hx, user_jac;
   double dinv[kGenMaxM], dp[kGenMaxM], dp_l2, scal;
 };
 
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(kGenThreads) void gen_pass_kernel(GenArgs a) {
     for (int i = tid; i < n; i += kGenThreads) a.hx_rw[i] = a.aux[i];
   } else if (a.kind == RQ_DIF_TRIAL) {
     for (int i = tid; i < n; i += kGenThreads) a.wrk[i] = a.aux[i];
-  } else if (a.kind == RQ_JAC || a.kind == RQ_DIF_JAC) {  // misc_core.c:167-170 / :206-209
+  } else if ((a.kind == RQ_JAC || a.kind == RQ_DIF_JAC) && !a.user_jac) {  // misc_core.c:167-170 / :206-209
     for (int i = tid; i < n; i += kGenThreads)
       for (int j = 0; j < m; ++j) {
         const double v = a.central ? (a.aux[(size_t)(2 * j + 1) * n + i] - a.aux[(size_t)(2 * j) * n + i])
@@ -223,6 +223,7 @@ __global__ __launch_bounds__(kGenThreads) void gen_pass_kernel(GenArgs a) {
   } while (0)
 
 typedef void (*user_func_t)(double *p, double *hx, int m, int n, void *adata);
+typedef void (*user_jacf_t)(double *p, double *jac, int m, int n, void *adata);
 
 namespace {
 
@@ -235,7 +236,7 @@ struct GenBuffers {
 };
 
 template <int M, int METHOD>
-int generic_run(user_func_t func, double *p, double *x, int n, double *lb, double *ub, double *dscl, int itmax,
+int generic_run(user_func_t func, user_jacf_t jacf, double *p, double *x, int n, double *lb, double *ub, double *dscl, int itmax,
                 double *opts, double *info, double *covar, void *adata) {
   using Machine = typename std::conditional<METHOD == 0, DifMachine<M>, BcMachine<M>>::type;
   Machine mach;
@@ -243,6 +244,7 @@ int generic_run(user_func_t func, double *p, double *x, int n, double *lb, doubl
     mach.start(p, n, itmax, opts, covar != nullptr, /*speculative=*/0);
   else
     mach.start(p, n, lb, ub, dscl, itmax, opts, covar != nullptr);
+  if constexpr (METHOD == 1) mach.c.analytic_jac = jacf ? 1 : 0;
   if (mach.h.req.kind == RQ_DONE) {
     if constexpr (METHOD == 1) {
       if (mach.c.bad_input == 2) {
@@ -322,7 +324,20 @@ int generic_run(user_func_t func, double *p, double *x, int n, double *lb, doubl
       func(pt, host_aux.data(), M, n, adata);
       planes = 1;
       break;
-    case RQ_JAC:  // bc_dif re-evaluates f(p) on every Jacobian (lmbc_core.c:1049); forward only
+    case RQ_JAC:
+      if (jacf) {  // dlevmar_bc_der: the caller's analytic Jacobian (lmbc_core.c:555-557).  The residual paired with
+                   // J^T e is x - f(p) of the accepted point; f is deterministic, so it is simply evaluated again here
+        std::vector<double> jh((size_t)n * M);
+        for (int j = 0; j < M; ++j) pt[j] = r.p[j];
+        func(pt, host_aux.data(), M, n, adata);
+        HIP_OK(hipMemcpy(d_hx, host_aux.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+        for (int j = 0; j < M; ++j) pt[j] = r.p[j];
+        jacf(pt, jh.data(), M, n, adata);
+        HIP_OK(hipMemcpy(d_jac, jh.data(), sizeof(double) * (size_t)n * M, hipMemcpyHostToDevice));
+        a.user_jac = 1;
+        break;
+      }
+      // bc_dif re-evaluates f(p) on every Jacobian (lmbc_core.c:1049); forward only
       if (!r.central) {
         for (int j = 0; j < M; ++j) pt[j] = r.p[j];
         func(pt, host_aux.data() + (size_t)M * n, M, n, adata);  // parked behind the M difference planes
@@ -379,17 +394,17 @@ int generic_run(user_func_t func, double *p, double *x, int n, double *lb, doubl
 }
 
 template <int METHOD>
-int generic_dispatch(user_func_t func, double *p, double *x, int m, int n, double *lb, double *ub, double *dscl, int itmax,
+int generic_dispatch(user_func_t func, user_jacf_t jacf, double *p, double *x, int m, int n, double *lb, double *ub, double *dscl, int itmax,
                      double *opts, double *info, double *covar, void *adata) {
   switch (m) {
-  case 1: return generic_run<1, METHOD>(func, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
-  case 2: return generic_run<2, METHOD>(func, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
-  case 3: return generic_run<3, METHOD>(func, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
-  case 4: return generic_run<4, METHOD>(func, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
-  case 5: return generic_run<5, METHOD>(func, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
-  case 6: return generic_run<6, METHOD>(func, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
-  case 7: return generic_run<7, METHOD>(func, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
-  case 8: return generic_run<8, METHOD>(func, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
+  case 1: return generic_run<1, METHOD>(func, jacf, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
+  case 2: return generic_run<2, METHOD>(func, jacf, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
+  case 3: return generic_run<3, METHOD>(func, jacf, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
+  case 4: return generic_run<4, METHOD>(func, jacf, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
+  case 5: return generic_run<5, METHOD>(func, jacf, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
+  case 6: return generic_run<6, METHOD>(func, jacf, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
+  case 7: return generic_run<7, METHOD>(func, jacf, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
+  case 8: return generic_run<8, METHOD>(func, jacf, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
   }
   set_error("generic callback path supports 1 <= m <= %d parameters (got %d)", kGenMaxM, m);
   return kLmError;
@@ -397,15 +412,15 @@ int generic_dispatch(user_func_t func, double *p, double *x, int m, int n, doubl
 
 }  // namespace
 
-int generic_fit_run(int method, user_func_t func, double *p, double *x, int m, int n, double *lb, double *ub, double *dscl,
-                    int itmax, double *opts, double *info, double *covar, void *adata) {
+int generic_fit_run(int method, user_func_t func, user_jacf_t jacf, double *p, double *x, int m, int n, double *lb, double *ub,
+                    double *dscl, int itmax, double *opts, double *info, double *covar, void *adata) {
   if (!func || !p || n <= 0) {
     set_error("generic fit: null callback / parameter vector or n <= 0");
     return kLmError;
   }
   (void)hipGetLastError();
-  if (method == 0) return generic_dispatch<0>(func, p, x, m, n, lb, ub, dscl, itmax, opts, info, covar, adata);
-  return generic_dispatch<1>(func, p, x, m, n, lb, ub, dscl, itmax, opts, info, covar, adata);
+  if (method == 0) return generic_dispatch<0>(func, nullptr, p, x, m, n, lb, ub, dscl, itmax, opts, info, covar, adata);
+  return generic_dispatch<1>(func, jacf, p, x, m, n, lb, ub, dscl, itmax, opts, info, covar, adata);
 }
 
 }  // namespace brdf

@@ -577,6 +577,7 @@ struct BcMachine {
     int has_lb, has_ub, has_dscl;
     double lb[M], ub[M], dscl[M];
     int infeasible_mask, bad_input;
+    int analytic_jac;  // 1: dlevmar_bc_der (caller's Jacobian): no nfev correction at the end (lmbc_core.c:1119-1124)
     double p_start[M];
     double info[kInfoSz], covar[M * M];
     int ret;
@@ -651,6 +652,7 @@ struct BcMachine {
     c.has_lb = lb_ != nullptr;
     c.has_ub = ub_ != nullptr;
     c.has_dscl = dscl_ != nullptr;
+    c.analytic_jac = 0;
     h.k = 0;
     h.stop = 0;
     h.nu = 2;
@@ -1120,7 +1122,7 @@ struct BcMachine {
         c.info[4] = h.mu / m0;
         c.info[5] = (double)h.k;
         c.info[6] = (double)h.stop;
-        c.info[7] = (double)h.nfev + (double)h.njev * (c.o.forward ? (M + 1) : (2 * M));
+        c.info[7] = (double)h.nfev + (c.analytic_jac ? 0.0 : (double)h.njev * (c.o.forward ? (M + 1) : (2 * M)));
         c.info[8] = (double)h.njev;
         c.info[9] = (double)h.nlss;
         if (c.want_covar) {

@@ -353,6 +353,11 @@ def _product_kat(lib, pr):
     covar = np.zeros(m * m) if pr.get("covar") else None
     if pr["kind"] == "dif":
         r = lib.dlevmar_dif(fp, L.ptr(p), L.ptr(x), m, n, pr["itmax"], L.ptr(opts), L.ptr(info), None, L.ptr(covar), None)
+    elif pr["kind"] == "bc_der":
+        lb, ub = L.f64(pr["lb"]), L.f64(pr["ub"])
+        jp = C.cast(getattr(L.ref, pr["j"]), C.c_void_p)
+        r = lib.dlevmar_bc_der(fp, jp, L.ptr(p), L.ptr(x), m, n, L.ptr(lb), L.ptr(ub), None, pr["itmax"], L.ptr(opts),
+                               L.ptr(info), None, L.ptr(covar), None)
     else:
         lb, ub = L.f64(pr["lb"]), L.f64(pr["ub"])
         r = lib.dlevmar_bc_dif(fp, L.ptr(p), L.ptr(x), m, n, L.ptr(lb), L.ptr(ub), None, pr["itmax"], L.ptr(opts),
@@ -364,15 +369,16 @@ def _product_kat(lib, pr):
 def test_lmdemo_known_answers_through_the_product_abi(gpu, capfd):
     """generic_fit.hip: host callback evaluated on the host, residuals / FD Jacobian fill / J^T J / J^T e / Broyden on
     the device in the reference's summation order (small problems) -> the reference's known answers replay BIT FOR
-    BIT through dlevmar_dif / dlevmar_bc_dif of libbrdf_hip.so: Wood, Meyer (with covariance), and the five
-    box-constrained problems through the finite-difference entry point."""
+    BIT through dlevmar_dif / dlevmar_bc_der / dlevmar_bc_dif of libbrdf_hip.so: Wood, Meyer (with covariance), and
+    the five box-constrained problems both with their analytic Jacobians (the rows of SURVEY.md section 4) and
+    through the finite-difference entry point."""
     torch, brdf_amd, dev = gpu
     from brdf_amd._lib import lib
     from tests.kat_problems import PROBLEMS
     gold = json.load(open(os.path.join(HERE, "golden", "lmdemo_kat.json")))["kats"]
     ran = 0
     for kat in gold:
-        if kat["entry"] not in ("dif", "bc_dif"):
+        if kat["entry"] not in ("dif", "bc_dif", "bc_der"):
             continue
         r, p, info, covar = _product_kat(lib, PROBLEMS[kat["problem"]])
         hexs = lambda v: np.array([float.fromhex(s) for s in v])  # noqa: E731
@@ -382,7 +388,7 @@ def test_lmdemo_known_answers_through_the_product_abi(gpu, capfd):
         if kat["covar"] is not None:
             assert np.array_equal(covar, hexs(kat["covar"]))
         ran += 1
-    assert ran == 7
+    assert ran == 12  # Wood, Meyer; HS01, HS21, hatfldb, hatfldc, combustion through bc_der AND bc_dif
     capfd.readouterr()
 
 
