@@ -26,7 +26,10 @@ class ExtraData(C.Structure):
 ABI = {
     "dlevmar_dif": (C.c_int, [C.c_void_p, D, D, C.c_int, C.c_int, C.c_int, D, D, D, D, C.c_void_p]),
     "dlevmar_bc_dif": (C.c_int, [C.c_void_p, D, D, C.c_int, C.c_int, D, D, D, C.c_int, D, D, D, D, C.c_void_p]),
+    "dlevmar_der": (C.c_int, [C.c_void_p, C.c_void_p, D, D, C.c_int, C.c_int, C.c_int, D, D, D, D, C.c_void_p]),
     "dlevmar_bc_der": (C.c_int, [C.c_void_p, C.c_void_p, D, D, C.c_int, C.c_int, D, D, D, C.c_int, D, D, D, D, C.c_void_p]),
+    "dlevmar_stddev": (C.c_double, [D, C.c_int, C.c_int]),
+    "dlevmar_corcoef": (C.c_double, [D, C.c_int, C.c_int, C.c_int]),
     "brdf_hip_register_model": (C.c_int, [C.c_void_p]),
     "brdf_hip_unregister_model": (C.c_int, [C.c_void_p]),
     "BRDFFunc_hip": (None, [D, D, C.c_int, C.c_int, C.c_void_p]),

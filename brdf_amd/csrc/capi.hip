@@ -4,6 +4,7 @@
 // levmar.h:112-127 signatures and semantics (return value, info[], NULL-able opts/info/work/covar,
 // stderr diagnostics, LM_ERROR instead of exit()).  Everything n-sized runs in the HIP kernels of
 // stream_fit.hip / batch_fit.hip; there is no CPU evaluation path in this library.
+#include <cmath>
 #include <cstring>
 #include <mutex>
 
@@ -138,6 +139,21 @@ int dlevmar_bc_dif(void (*func)(double *, double *, int, int, void *), double *p
                   adata);
 }
 
+int dlevmar_der(void (*func)(double *, double *, int, int, void *), void (*jacf)(double *, double *, int, int, void *),
+                double *p, double *x, int m, int n, int itmax, double *opts, double *info, double * /*work*/, double *covar,
+                void *adata) {
+  if (!func) {
+    set_error("dlevmar_der(): func is NULL");
+    return LM_ERROR;
+  }
+  if (!jacf) {  // lm_core.c:126-130
+    set_error("No function specified for computing the Jacobian in dlevmar_der(). If no such function is available, use "
+              "dlevmar_dif() rather than dlevmar_der()");
+    return LM_ERROR;
+  }
+  return generic_fit_run(2, func, jacf, p, x, m, n, nullptr, nullptr, nullptr, itmax, opts, info, covar, adata);
+}
+
 int dlevmar_bc_der(void (*func)(double *, double *, int, int, void *), void (*jacf)(double *, double *, int, int, void *),
                    double *p, double *x, int m, int n, double *lb, double *ub, double *dscl, int itmax, double *opts,
                    double *info, double * /*work*/, double *covar, void *adata) {
@@ -152,6 +168,10 @@ int dlevmar_bc_der(void (*func)(double *, double *, int, int, void *), void (*ja
   }
   return generic_fit_run(BRDF_METHOD_BC_DIF, func, jacf, p, x, m, n, lb, ub, dscl, itmax, opts, info, covar, adata);
 }
+
+/* scalar post-processing of the covariance the solvers return (misc_core.c:598-611); no n-sized work */
+double dlevmar_stddev(double *covar, int m, int i) { return sqrt(covar[i * m + i]); }
+double dlevmar_corcoef(double *covar, int m, int i, int j) { return covar[i * m + j] / sqrt(covar[i * m + i] * covar[j * m + j]); }
 
 int brdf_hip_register_model(void (*func)(double *, double *, int, int, void *)) {
   if (!func) return -1;

@@ -238,12 +238,16 @@ struct GenBuffers {
 template <int M, int METHOD>
 int generic_run(user_func_t func, user_jacf_t jacf, double *p, double *x, int n, double *lb, double *ub, double *dscl, int itmax,
                 double *opts, double *info, double *covar, void *adata) {
-  using Machine = typename std::conditional<METHOD == 0, DifMachine<M>, BcMachine<M>>::type;
+  // METHOD: 0 dlevmar_dif, 1 dlevmar_bc_dif / dlevmar_bc_der, 2 dlevmar_der
+  using Machine = typename std::conditional<METHOD == 0, DifMachine<M>,
+                                            typename std::conditional<METHOD == 1, BcMachine<M>, DerMachine<M>>::type>::type;
   Machine mach;
   if constexpr (METHOD == 0)
     mach.start(p, n, itmax, opts, covar != nullptr, /*speculative=*/0);
-  else
+  else if constexpr (METHOD == 1)
     mach.start(p, n, lb, ub, dscl, itmax, opts, covar != nullptr);
+  else
+    mach.start(p, n, itmax, opts, covar != nullptr);
   if constexpr (METHOD == 1) mach.c.analytic_jac = jacf ? 1 : 0;
   if (mach.h.req.kind == RQ_DONE) {
     if constexpr (METHOD == 1) {
@@ -257,7 +261,7 @@ int generic_run(user_func_t func, user_jacf_t jacf, double *p, double *x, int n,
       }
     }
     set_error("%s(): cannot solve a problem with fewer measurements [%d] than unknowns [%d]",
-              METHOD == 0 ? "dlevmar_dif" : "dlevmar_bc_dif", n, M);
+              METHOD == 0 ? "dlevmar_dif" : (METHOD == 1 ? "dlevmar_bc_dif" : "dlevmar_der"), n, M);
     return kLmError;
   }
   if constexpr (METHOD == 1)
@@ -305,7 +309,7 @@ int generic_run(user_func_t func, user_jacf_t jacf, double *p, double *x, int n,
     a.central = r.central;
     a.exact = exact ? 1 : 0;
     a.accepted = r.aux;
-    a.bc_rule = METHOD;
+    a.bc_rule = (METHOD != 0);  // n*m < 1024 in bc_der and der (lmbc_core.c:573, lm_core.c:197), <= 1024 in dif (:594)
     a.scal = r.scal;
     a.dp_l2 = r.dp_l2;
     for (int j = 0; j < M; ++j) a.dp[j] = r.dp[j];
@@ -420,6 +424,7 @@ int generic_fit_run(int method, user_func_t func, user_jacf_t jacf, double *p, d
   }
   (void)hipGetLastError();
   if (method == 0) return generic_dispatch<0>(func, nullptr, p, x, m, n, lb, ub, dscl, itmax, opts, info, covar, adata);
+  if (method == 2) return generic_dispatch<2>(func, jacf, p, x, m, n, nullptr, nullptr, nullptr, itmax, opts, info, covar, adata);
   return generic_dispatch<1>(func, jacf, p, x, m, n, lb, ub, dscl, itmax, opts, info, covar, adata);
 }
 

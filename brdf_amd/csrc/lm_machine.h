@@ -1147,4 +1147,236 @@ struct BcMachine {
   }
 };
 
+// =================================================================================================
+// dlevmar_der: unconstrained LM with the caller's analytic Jacobian (lm_core.c:64-432).  Every outer
+// iteration asks for the Jacobian's normal equations (RQ_JAC: the pass executor fills J from the caller's
+// jacf instead of finite differences), then tries damped steps until one reduces the error.
+// =================================================================================================
+template <int M>
+struct DerMachine {
+  enum Phase : int { R_INIT_EVAL = 1, R_ITER_TOP, R_AFTER_JAC, R_SOLVE, R_AFTER_EVAL, R_END_ITER, R_FINISH, R_DONE };
+  struct Cold {
+    FitOptions o;
+    int itmax, n, want_covar;
+    double info[kInfoSz], covar[M * M];
+    int ret;
+  };
+  struct Hot {
+    int phase, k, stop, nu, nfev, njev, nlss;
+    double p[M], mu, p_e2, init_e2, jte_inf, p_l2, dp_l2, pdp_e2;
+    double jtj[M * M], jte[M], diag[M], dp[M], pdp[M];
+    Request<M> req;
+  };
+  Cold c;
+  Hot h;
+
+  static LM_HD void clear_req(Hot &h) {
+    h.req.kind = RQ_DONE;
+    h.req.central = 0;
+    h.req.sel_hx = h.req.sel_j = h.req.aux = 0;
+    h.req.dp_l2 = 0.0;
+    h.req.scal = 1.0;
+    for (int i = 0; i < M; ++i) h.req.p[i] = h.req.d[i] = h.req.q[i] = h.req.dp[i] = 0.0;
+  }
+
+  LM_HD void start(const double *p0, int n_, int itmax_, const double *opts, int want_covar_) {
+    c.o = make_options(opts);
+    c.itmax = itmax_;
+    c.n = n_;
+    c.want_covar = want_covar_;
+    h.k = h.stop = 0;
+    h.nu = 2;
+    h.nfev = h.njev = h.nlss = 0;
+    h.mu = h.jte_inf = h.p_l2 = h.p_e2 = h.init_e2 = h.pdp_e2 = 0.0;
+    h.dp_l2 = DBL_MAX;
+    c.ret = kLmError;
+    for (int i = 0; i < M; ++i) {
+      h.p[i] = p0[i];
+      h.jte[i] = h.diag[i] = h.dp[i] = h.pdp[i] = 0.0;
+    }
+    for (int i = 0; i < M * M; ++i) h.jtj[i] = c.covar[i] = 0.0;
+    for (int i = 0; i < kInfoSz; ++i) c.info[i] = 0.0;
+    clear_req(h);
+    if (c.n < M) {  // lm_core.c:121-124
+      h.phase = R_DONE;
+      return;
+    }
+    h.req.kind = RQ_EVAL;
+    for (int i = 0; i < M; ++i) h.req.p[i] = h.p[i];
+    h.phase = R_INIT_EVAL;
+  }
+
+  LM_HD void step(const double *s, double /*maxabs*/) {
+    int ph = h.phase;
+    for (;;) {
+      switch (ph) {
+      case R_INIT_EVAL:  // lm_core.c:168-179
+        h.nfev = 1;
+        h.p_e2 = s[0];
+        h.init_e2 = h.p_e2;
+        if (!lm_finite(h.p_e2)) h.stop = 7;
+        ph = R_ITER_TOP;
+        break;
+
+      case R_ITER_TOP:
+        if (!(h.k < c.itmax && !h.stop)) {
+          ph = R_FINISH;
+          break;
+        }
+        if (h.p_e2 <= c.o.eps3) {
+          h.stop = 6;
+          ph = R_FINISH;
+          break;
+        }
+        clear_req(h);
+        h.req.kind = RQ_JAC;
+        for (int i = 0; i < M; ++i) h.req.p[i] = h.p[i];
+        ++h.njev;
+        ph = R_AFTER_JAC;
+        h.phase = ph;
+        return;
+
+      case R_AFTER_JAC: {  // lm_core.c:262-291
+        unpack_lower<M>(s, h.jtj);
+        for (int i = 0; i < M; ++i) h.jte[i] = s[SumLayout<M>::NL + i];
+        h.p_l2 = h.jte_inf = 0.0;
+        for (int i = 0; i < M; ++i) {
+          const double t = lm_abs(h.jte[i]);
+          if (h.jte_inf < t) h.jte_inf = t;
+          h.diag[i] = h.jtj[i * M + i];
+          h.p_l2 += h.p[i] * h.p[i];
+        }
+        if (h.jte_inf <= c.o.eps1) {
+          h.dp_l2 = 0.0;
+          h.stop = 1;
+          ph = R_FINISH;
+          break;
+        }
+        if (h.k == 0) {
+          double t = -DBL_MAX;
+          for (int i = 0; i < M; ++i)
+            if (h.diag[i] > t) t = h.diag[i];
+          h.mu = c.o.tau * t;
+        }
+        ph = R_SOLVE;
+        break;
+      }
+
+      case R_SOLVE: {  // the inner while(1), lm_core.c:294-397
+        for (int i = 0; i < M; ++i) h.jtj[i * M + i] += h.mu;
+        const int solved = lu_solve<M>(h.jtj, h.jte, h.dp);
+        ++h.nlss;
+        if (solved) {
+          h.dp_l2 = 0.0;
+          for (int i = 0; i < M; ++i) {
+            const double t = h.dp[i];
+            h.pdp[i] = h.p[i] + t;
+            h.dp_l2 += t * t;
+          }
+          if (h.dp_l2 <= c.o.eps2sq * h.p_l2) {
+            h.stop = 2;
+            ph = R_END_ITER;
+            break;
+          }
+          if (h.dp_l2 >= (h.p_l2 + c.o.eps2) / (kEpsilon * kEpsilon)) {
+            h.stop = 4;
+            ph = R_END_ITER;
+            break;
+          }
+          clear_req(h);
+          h.req.kind = RQ_EVAL;
+          for (int i = 0; i < M; ++i) h.req.p[i] = h.pdp[i];
+          ++h.nfev;
+          ph = R_AFTER_EVAL;
+          h.phase = ph;
+          return;
+        }
+        // unsolvable system: treat as a rejected step
+        h.mu *= h.nu;
+        {
+          const int nu2 = (int)((unsigned)h.nu << 1);
+          if (nu2 <= h.nu) {
+            h.stop = 5;
+            ph = R_END_ITER;
+            break;
+          }
+          h.nu = nu2;
+        }
+        for (int i = 0; i < M; ++i) h.jtj[i * M + i] = h.diag[i];
+        break;  // solve again
+      }
+
+      case R_AFTER_EVAL: {  // lm_core.c:347-396
+        h.pdp_e2 = s[0];
+        if (!lm_finite(h.pdp_e2)) {
+          h.stop = 7;
+          ph = R_END_ITER;
+          break;
+        }
+        double dL = 0.0;
+        for (int i = 0; i < M; ++i) dL += h.dp[i] * (h.mu * h.dp[i] + h.jte[i]);
+        const double dF = h.p_e2 - h.pdp_e2;
+        if (dL > 0.0 && dF > 0.0) {
+          double t = (2.0 * dF / dL - 1.0);
+          t = 1.0 - t * t * t;
+          h.mu = h.mu * ((t >= kOneThird) ? t : kOneThird);
+          h.nu = 2;
+          for (int i = 0; i < M; ++i) h.p[i] = h.pdp[i];
+          h.p_e2 = h.pdp_e2;
+          ph = R_END_ITER;
+          break;
+        }
+        h.mu *= h.nu;
+        {
+          const int nu2 = (int)((unsigned)h.nu << 1);
+          if (nu2 <= h.nu) {
+            h.stop = 5;
+            ph = R_END_ITER;
+            break;
+          }
+          h.nu = nu2;
+        }
+        for (int i = 0; i < M; ++i) h.jtj[i * M + i] = h.diag[i];
+        ph = R_SOLVE;
+        break;
+      }
+
+      case R_END_ITER:
+        ++h.k;
+        ph = R_ITER_TOP;
+        break;
+
+      case R_FINISH: {  // lm_core.c:400-431
+        if (h.k >= c.itmax) h.stop = 3;
+        for (int i = 0; i < M; ++i) h.jtj[i * M + i] = h.diag[i];
+        c.info[0] = h.init_e2;
+        c.info[1] = h.p_e2;
+        c.info[2] = h.jte_inf;
+        c.info[3] = h.dp_l2;
+        double t = -DBL_MAX;
+        for (int i = 0; i < M; ++i)
+          if (t < h.jtj[i * M + i]) t = h.jtj[i * M + i];
+        c.info[4] = h.mu / t;
+        c.info[5] = (double)h.k;
+        c.info[6] = (double)h.stop;
+        c.info[7] = (double)h.nfev;
+        c.info[8] = (double)h.njev;
+        c.info[9] = (double)h.nlss;
+        if (c.want_covar) lu_covar<M>(h.jtj, c.covar, h.p_e2, c.n);
+        c.ret = (h.stop != 4 && h.stop != 7) ? h.k : kLmError;
+        clear_req(h);
+        ph = R_DONE;
+        h.phase = ph;
+        return;
+      }
+
+      default:
+        h.req.kind = RQ_DONE;
+        h.phase = ph;
+        return;
+      }
+    }
+  }
+};
+
 }  // namespace brdf

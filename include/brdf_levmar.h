@@ -60,6 +60,12 @@ int dlevmar_bc_dif(void (*func)(double *p, double *hx, int m, int n, void *adata
                    int m, int n, double *lb, double *ub, double *dscl, int itmax, double *opts,
                    double *info, double *work, double *covar, void *adata);
 
+/* Replaces dlevmar_der, levmar/levmar.h:106-110 (body lm_core.c:64-432): unconstrained LM with the caller's
+ * analytic Jacobian.  Host callbacks on the host, n-sized work on the device (generic path, 1 <= m <= 8). */
+int dlevmar_der(void (*func)(double *p, double *hx, int m, int n, void *adata),
+                void (*jacf)(double *p, double *j, int m, int n, void *adata), double *p, double *x, int m, int n,
+                int itmax, double *opts, double *info, double *work, double *covar, void *adata);
+
 /* Replaces dlevmar_bc_der, levmar/levmar.h:118-122 (body lmbc_core.c:369-1022): box-constrained LM with the
  * caller's analytic Jacobian jacf (row-major n x m, jac[i*m+j]).  func and jacf are host callbacks and are
  * called on the host; the residuals, J^T J, J^T e run on the device (generic path, 1 <= m <= 8). */
@@ -67,6 +73,11 @@ int dlevmar_bc_der(void (*func)(double *p, double *hx, int m, int n, void *adata
                    void (*jacf)(double *p, double *j, int m, int n, void *adata), double *p, double *x, int m, int n,
                    double *lb, double *ub, double *dscl, int itmax, double *opts, double *info, double *work,
                    double *covar, void *adata);
+
+/* levmar/levmar.h:357-361 (misc_core.c:598-611): standard deviation / Pearson correlation of the fitted
+ * parameters from the m x m covariance returned through `covar`. */
+double dlevmar_stddev(double *covar, int m, int i);
+double dlevmar_corcoef(double *covar, int m, int i, int j);
 
 /* Declares that `func` has the semantics of the reference's BRDFFunc (brdfdata.cpp:969-989): adata
  * points to a struct laid out like brdf_extra_data and the value depends on modelInfo.  A host

@@ -483,6 +483,138 @@ int orc_dlevmar_dif(orc_func_t f, double *p, double *x, int m, int n, int itmax,
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * Unconstrained LM with the caller's analytic Jacobian.  lm_core.c:64-432.
+ * ---------------------------------------------------------------------------------------------- */
+int orc_dlevmar_der(orc_func_t f, orc_jacf_t jf, double *p, double *x, int m, int n, int itmax, double *opts,
+                    double *info, double *work, double *covar, void *adata)
+{
+  double *e, *hx, *jte, *jac, *jtj, *dp, *diag, *pdp;
+  double tau, eps1, eps2, eps2sq, eps3;
+  double mu = 0.0, tmp, p_e2, jte_inf = 0.0, pdp_e2, p_l2 = 0.0, dp_l2 = DBL_MAX, dF, dL, init_e2;
+  int i, k, own_work = 0, solved, nu = 2, stop = 0, nfev, njev = 0, nlss = 0;
+  const int nm = n * m;
+
+  if (n < m) {
+    fprintf(stderr, "orc_dlevmar_der(): cannot solve a problem with fewer measurements [%d] than unknowns [%d]\n", n, m);
+    return ORC_ERROR;
+  }
+  if (!jf) return ORC_ERROR;
+  read_opts(opts, &tau, &eps1, &eps2, &eps2sq, &eps3);
+  if (!work) {
+    work = (double *)malloc((size_t)(2 * n + 4 * m + n * m + m * m) * sizeof(double)); /* levmar.h:68 */
+    if (!work) return ORC_ERROR;
+    own_work = 1;
+  }
+  e = work;
+  hx = e + n;
+  jte = hx + n;
+  jac = jte + m;
+  jtj = jac + nm;
+  dp = jtj + m * m;
+  diag = dp + m;
+  pdp = diag + m;
+
+  f(p, hx, m, n, adata);
+  nfev = 1;
+  p_e2 = orc_l2_residual(e, x, hx, n);
+  init_e2 = p_e2;
+  if (!isfinite(p_e2)) stop = 7;
+
+  for (k = 0; k < itmax && !stop; ++k) {
+    if (p_e2 <= eps3) {
+      stop = 6;
+      break;
+    }
+    jf(p, jac, m, n, adata);
+    ++njev;
+    if (nm < K_BLOCK * K_BLOCK)
+      jtj_jte_small(jac, e, jtj, jte, n, m);
+    else
+      jtj_jte_large(jac, e, jtj, jte, n, m);
+    for (i = 0, p_l2 = jte_inf = 0.0; i < m; ++i) {
+      if (jte_inf < (tmp = absd(jte[i]))) jte_inf = tmp;
+      diag[i] = jtj[i * m + i];
+      p_l2 += p[i] * p[i];
+    }
+    if (jte_inf <= eps1) {
+      dp_l2 = 0.0;
+      stop = 1;
+      break;
+    }
+    if (k == 0) {
+      for (i = 0, tmp = -DBL_MAX; i < m; ++i)
+        if (diag[i] > tmp) tmp = diag[i];
+      mu = tau * tmp;
+    }
+    for (;;) { /* damped steps until one reduces the error */
+      for (i = 0; i < m; ++i) jtj[i * m + i] += mu;
+      solved = orc_lu_solve(jtj, jte, dp, m);
+      ++nlss;
+      if (solved) {
+        for (i = 0, dp_l2 = 0.0; i < m; ++i) {
+          pdp[i] = p[i] + (tmp = dp[i]);
+          dp_l2 += tmp * tmp;
+        }
+        if (dp_l2 <= eps2sq * p_l2) {
+          stop = 2;
+          break;
+        }
+        if (dp_l2 >= (p_l2 + eps2) / (K_EPSILON * K_EPSILON)) {
+          stop = 4;
+          break;
+        }
+        f(pdp, hx, m, n, adata);
+        ++nfev;
+        pdp_e2 = orc_l2_residual(hx, x, hx, n);
+        if (!isfinite(pdp_e2)) {
+          stop = 7;
+          break;
+        }
+        for (i = 0, dL = 0.0; i < m; ++i) dL += dp[i] * (mu * dp[i] + jte[i]);
+        dF = p_e2 - pdp_e2;
+        if (dL > 0.0 && dF > 0.0) {
+          tmp = (2.0 * dF / dL - 1.0);
+          tmp = 1.0 - tmp * tmp * tmp;
+          mu = mu * ((tmp >= K_ONE_THIRD) ? tmp : K_ONE_THIRD);
+          nu = 2;
+          for (i = 0; i < m; ++i) p[i] = pdp[i];
+          for (i = 0; i < n; ++i) e[i] = hx[i];
+          p_e2 = pdp_e2;
+          break;
+        }
+      }
+      mu *= nu;
+      {
+        const int nu2 = nu << 1;
+        if (nu2 <= nu) {
+          stop = 5;
+          break;
+        }
+        nu = nu2;
+      }
+      for (i = 0; i < m; ++i) jtj[i * m + i] = diag[i];
+    }
+  }
+  if (k >= itmax) stop = 3;
+  for (i = 0; i < m; ++i) jtj[i * m + i] = diag[i];
+  if (info) {
+    info[0] = init_e2;
+    info[1] = p_e2;
+    info[2] = jte_inf;
+    info[3] = dp_l2;
+    info[4] = mu / max_diag(jtj, m);
+    info[5] = (double)k;
+    info[6] = (double)stop;
+    info[7] = (double)nfev;
+    info[8] = (double)njev;
+    info[9] = (double)nlss;
+  }
+  if (covar) orc_covar(jtj, covar, p_e2, m, n);
+  if (own_work) free(work);
+  return (stop != 4 && stop != 7) ? k : ORC_ERROR;
+}
+
+/* ------------------------------------------------------------------------------------------------
  * Box-constrained LM.  lmbc_core.c.
  * ---------------------------------------------------------------------------------------------- */
 static double median3(double a, double b, double c) /* lmbc_core.c:59-61 */

@@ -7,6 +7,7 @@
  * extension.
  *
  * What is restated (reference = /root/reference, levmar 2.6 as vendored by ccalantzis/BRDF):
+ *   orc_dlevmar_der      <- levmar/lm_core.c:64-432      (LM with the caller's analytic Jacobian)
  *   orc_dlevmar_dif      <- levmar/lm_core.c:438-842     (LM, FD Jacobian + Broyden rank-1 updates)
  *   orc_dlevmar_bc_der   <- levmar/lmbc_core.c:369-1022  (projected LM + line search + proj. gradient)
  *   orc_dlevmar_bc_dif   <- levmar/lmbc_core.c:1062-1129 (FD shim over bc_der)
@@ -53,6 +54,8 @@ int orc_lu_solve(const double *A, const double *B, double *x, int m);
 int orc_covar(const double *JtJ, double *C, double sumsq, int m, int n);
 
 int orc_dlevmar_dif(orc_func_t f, double *p, double *x, int m, int n, int itmax, double *opts,
+                    double *info, double *work, double *covar, void *adata);
+int orc_dlevmar_der(orc_func_t f, orc_jacf_t jf, double *p, double *x, int m, int n, int itmax, double *opts,
                     double *info, double *work, double *covar, void *adata);
 int orc_dlevmar_bc_der(orc_func_t f, orc_jacf_t jf, double *p, double *x, int m, int n, double *lb,
                        double *ub, double *dscl, int itmax, double *opts, double *info, double *work,

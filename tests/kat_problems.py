@@ -10,7 +10,16 @@ OPTS = (1e-3, 1e-15, 1e-15, 1e-20, 1e-6)  # lmdemo.c:816-817
 MEYER_X = [34.780, 28.610, 23.650, 19.630, 16.370, 13.720, 11.540, 9.744, 8.261, 7.030, 6.005, 5.147, 4.427, 3.820,
            3.307, 2.872]
 
+OSBORNE_X = [8.44E-1, 9.08E-1, 9.32E-1, 9.36E-1, 9.25E-1, 9.08E-1, 8.81E-1, 8.5E-1, 8.18E-1, 7.84E-1, 7.51E-1, 7.18E-1,
+             6.85E-1, 6.58E-1, 6.28E-1, 6.03E-1, 5.8E-1, 5.58E-1, 5.38E-1, 5.22E-1, 5.06E-1, 4.9E-1, 4.78E-1, 4.67E-1,
+             4.57E-1, 4.48E-1, 4.38E-1, 4.31E-1, 4.24E-1, 4.2E-1, 4.14E-1, 4.11E-1, 4.06E-1]
+
 PROBLEMS = {
+    0: dict(kind="der", f="ros", j="jacros", p=[-1.2, 1.0], x=[0, 0], itmax=1000),
+    1: dict(kind="der", f="modros", j="jacmodros", p=[-1.2, 1.0], x=[0, 0, 0], itmax=1000),
+    2: dict(kind="der", f="powell", j="jacpowell", p=[3.0, 1.0], x=[0, 0], itmax=1000),
+    5: dict(kind="der", f="osborne", j="jacosborne", p=[0.5, 1.5, -1.0, 1.0E-2, 2.0E-2], x=OSBORNE_X, itmax=1000),
+    6: dict(kind="der", f="helval", j="jachelval", p=[-1.0, 0.0, 0.0], x=[0, 0, 0], itmax=1000),
     3: dict(kind="dif", f="wood", p=[-3, -1, -3, -1], x=[0] * 6, itmax=1000),
     4: dict(kind="dif", f="meyer", p=[8.85, 4.0, 2.5], x=MEYER_X, itmax=1000, covar=True),
     11: dict(kind="bc_der", f="hs01", j="jachs01", p=[-2, 1], x=[0, 0], lb=[-DM, -1.5], ub=[DM, DM], itmax=1000),
@@ -29,6 +38,11 @@ for _k in (11, 12, 13, 14, 15):
 
 # what the reference's lmdemo prints ("%.7g" solution; iters, reason, nfev, njev, nlss)
 SURVEY_TABLE = {
+    0: ("0.9432309 0.8893884", (1000, 3, 1290, 1000, 1289)),
+    1: ("0.9999992 0.9999984", (14, 2, 25, 14, 25)),
+    2: ("-9.00243e-11 -6.719414e-05", (198, 6, 208, 198, 207)),
+    5: ("0.3754101 1.935847 -1.464687 0.01286753 0.0221227", (34, 2, 45, 34, 45)),
+    6: ("1 3.691042e-13 5.857861e-13", (9, 6, 10, 9, 9)),
     3: ("1 1 1 1", (113, 6, 158, 11, 113)),
     4: ("2.481778 6.181346 3.502236", (209, 2, 273, 21, 210)),
     11: ("1 1", (14, 6, 23, 14, 14)),
@@ -53,6 +67,9 @@ def run_problem(lib, prefix, pr, ref_lib=None):
     if pr["kind"] == "dif":
         fn = getattr(lib, prefix + "dlevmar_dif")
         r = fn(fp(pr["f"]), ptr(p), ptr(x), m, n, pr["itmax"], ptr(opts), ptr(info), None, ptr(covar), None)
+    elif pr["kind"] == "der":
+        fn = getattr(lib, prefix + "dlevmar_der")
+        r = fn(fp(pr["f"]), fp(pr["j"]), ptr(p), ptr(x), m, n, pr["itmax"], ptr(opts), ptr(info), None, ptr(covar), None)
     else:
         lb, ub = f64(pr["lb"]), f64(pr["ub"])
         if pr["kind"] == "bc_der":

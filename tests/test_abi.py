@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_symbols():
     text = open(os.path.join(ROOT, "include", "brdf_levmar.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    names = re.findall(r"^(?:int|void|const char \*)\s*\*?\s*(\w+)\s*\(", text, flags=re.M)
+    names = re.findall(r"^(?:int|void|double|const char \*)\s*\*?\s*(\w+)\s*\(", text, flags=re.M)
     return sorted(set(names))
 
 
@@ -73,3 +73,14 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
         importlib.reload(m)
     monkeypatch.delenv("BRDF_HIP_LIB")
     importlib.reload(m)
+
+
+def test_covariance_helpers():
+    """dlevmar_stddev / dlevmar_corcoef (misc_core.c:598-611) on the Meyer covariance printed by the reference's
+    lmdemo: sigma_0 = sqrt(0.00483514)"""
+    from brdf_amd._lib import D, lib
+    import json
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "lmdemo_kat.json")))["kats"]
+    covar = np.array([float.fromhex(s) for s in next(k for k in gold if k["problem"] == 4)["covar"]])
+    assert lib.dlevmar_stddev(covar.ctypes.data_as(D), 3, 0) == np.sqrt(covar[0])
+    assert lib.dlevmar_corcoef(covar.ctypes.data_as(D), 3, 0, 1) == covar[1] / np.sqrt(covar[0] * covar[4])

@@ -353,6 +353,9 @@ def _product_kat(lib, pr):
     covar = np.zeros(m * m) if pr.get("covar") else None
     if pr["kind"] == "dif":
         r = lib.dlevmar_dif(fp, L.ptr(p), L.ptr(x), m, n, pr["itmax"], L.ptr(opts), L.ptr(info), None, L.ptr(covar), None)
+    elif pr["kind"] == "der":
+        jp = C.cast(getattr(L.ref, pr["j"]), C.c_void_p)
+        r = lib.dlevmar_der(fp, jp, L.ptr(p), L.ptr(x), m, n, pr["itmax"], L.ptr(opts), L.ptr(info), None, L.ptr(covar), None)
     elif pr["kind"] == "bc_der":
         lb, ub = L.f64(pr["lb"]), L.f64(pr["ub"])
         jp = C.cast(getattr(L.ref, pr["j"]), C.c_void_p)
@@ -378,7 +381,7 @@ def test_lmdemo_known_answers_through_the_product_abi(gpu, capfd):
     gold = json.load(open(os.path.join(HERE, "golden", "lmdemo_kat.json")))["kats"]
     ran = 0
     for kat in gold:
-        if kat["entry"] not in ("dif", "bc_dif", "bc_der"):
+        if kat["entry"] not in ("der", "dif", "bc_dif", "bc_der"):
             continue
         r, p, info, covar = _product_kat(lib, PROBLEMS[kat["problem"]])
         hexs = lambda v: np.array([float.fromhex(s) for s in v])  # noqa: E731
@@ -388,7 +391,7 @@ def test_lmdemo_known_answers_through_the_product_abi(gpu, capfd):
         if kat["covar"] is not None:
             assert np.array_equal(covar, hexs(kat["covar"]))
         ran += 1
-    assert ran == 12  # Wood, Meyer; HS01, HS21, hatfldb, hatfldc, combustion through bc_der AND bc_dif
+    assert ran == 17  # all twelve no-LAPACK lmdemo problems + the five bc ones through bc_dif
     capfd.readouterr()
 
 
