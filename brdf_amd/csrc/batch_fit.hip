@@ -456,6 +456,8 @@ BatchFn pick(int model, int method, bool fast) {
 struct Geometry {
   int threads, spt;
 };
+// (measured and rejected for 1024 < n <= 4096, bc_dif: 256 threads x 16 samples per lane to get two workgroups per
+// CU -- the fully unrolled 16-sample sweep spills ~1.2 KB per lane and runs 2x slower than 512 x 8)
 // one wavefront per fit up to 256 samples, one workgroup per fit up to 4096
 bool geometry_for(int n, Geometry *g) {
   if (n <= 64) *g = {64, 1};
