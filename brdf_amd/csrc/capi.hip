@@ -73,10 +73,6 @@ int host_fit(int method, const char *who, model_func_t func, double *p, double *
     set_error("%s(): adata (struct extraData) and p must not be NULL", who);
     return LM_ERROR;
   }
-  if (!x) {
-    set_error("%s(): x == NULL (zero measurements) is not supported by the HIP path", who);
-    return LM_ERROR;
-  }
   const brdf_extra_data *ed = static_cast<const brdf_extra_data *>(adata);
   if (!ed->angles) {
     set_error("%s(): extraData.angles is NULL", who);
@@ -97,7 +93,8 @@ int host_fit(int method, const char *who, model_func_t func, double *p, double *
     e = hipMemcpy(angles.ptr + n, ed->angles + n, sizeof(double) * n, hipMemcpyHostToDevice);
   if (e == hipSuccess && need2)
     e = hipMemcpy(angles.ptr + 2 * (size_t)n, ed->angles + 2 * (size_t)n, sizeof(double) * n, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(xs.ptr, x, sizeof(double) * n, hipMemcpyHostToDevice);
+  if (e == hipSuccess)  // "NULL implies a zero vector", lm_core.c:441 / misc_core.c:770
+    e = x ? hipMemcpy(xs.ptr, x, sizeof(double) * n, hipMemcpyHostToDevice) : hipMemset(xs.ptr, 0, sizeof(double) * n);
   if (e != hipSuccess) {
     set_error("%s(): host->device copy failed: %s", who, hipGetErrorString(e));
     return LM_ERROR;

@@ -45,7 +45,7 @@ enum { BRDF_METHOD_DIF = 0, BRDF_METHOD_BC_DIF = 1 };
  * value (#iterations or LM_ERROR) and info[0..9] meaning.  `work` is accepted and ignored (the
  * scratch lives in HBM); nothing is written to it.
  *   - `func` registered with brdf_hip_register_model (or BRDFFunc_hip): the BRDF model is evaluated by the
- *     library's device code, m must be 3, x must not be NULL.
+ *     library's device code, m must be 3 (x == NULL means a zero measurement vector, as in levmar).
  *   - any other `func`, 1 <= m <= 8: `func` is called on the host (it is the caller's code), all n-sized work
  *     around it runs on the device; small problems (n*m <= 65536) are summed in the reference's order and
  *     reproduce levmar bit for bit. */

@@ -20,3 +20,12 @@ for model in (2, 1):
             print(f"model={model} method={method} ret={r.ret} p={r.p} nfev={r.info[7]:.0f} wall={dt*1e3:.3f} ms "
                   f"dev={st['device_us']:.1f} us passes={st['passes']} us/pass={st['device_us']/max(1,st['passes']):.2f} "
                   f"evals/s={r.info[7]*n/dt:.3e}", flush=True)
+
+# PCIe-inclusive: the drop-in entry point with HOST pointers (allocation + 32 MB upload + fit), Ward 1M
+angles, x, _ = synth.make_single(2, 1_000_000)
+for method in (0, 1):
+    for rep in range(3):
+        t0 = time.perf_counter()
+        r = brdf_amd.host_dlevmar(method, 2, angles, x, synth.P0[2], lb=synth.LB, ub=synth.UB, itmax=100, opts=synth.OPTS)
+        dt = time.perf_counter() - t0
+    print(f"host-pointer drop-in method={method}: {dt*1e3:.3f} ms per call, {r.info[7]*1e6/dt:.3e} evals/s (PCIe + allocation inclusive)", flush=True)

@@ -422,3 +422,32 @@ def test_unregistered_brdf_callback_takes_the_generic_path(gpu):
     _, p_ref, info_ref = L.brdf_fit("orc", 1, model, angles, x, synth.P0[model], synth.ITMAX, synth.OPTS, synth.LB, synth.UB)
     assert rc >= 0 and len(calls) == info[7]
     assert L.rel_err(p, p_ref) <= 1e-6 and abs(info[1] - info_ref[1]) <= 1e-9 * info_ref[1]
+
+
+def test_host_batch_entry_point_and_null_measurements(gpu):
+    """brdf_hip_fit_batch (host pointers: the CalcBRDFEquation loop as one call, brdfdata.cpp:1195-1220) and
+    x == NULL ("a zero vector", lm_core.c:441)"""
+    torch, brdf_amd, dev = gpu
+    from brdf_amd._lib import D, ExtraData, lib
+    model, n, S = 1, 16, 40
+    angles, x, _ = synth.make_surfels(model, n, first=500, count=S)
+    p = np.tile(np.array(synth.P0[model]), (S, 1))
+    info = np.zeros((S, 10))
+    ret = np.zeros(S, dtype=np.int32)
+    lb, ub, opts = np.array(synth.LB), np.array(synth.UB), np.array(synth.OPTS)
+    bad = lib.brdf_hip_fit_batch(1, model, angles.ctypes.data_as(D), x.ctypes.data_as(D), S, n, p.ctypes.data_as(D),
+                                 lb.ctypes.data_as(D), ub.ctypes.data_as(D), synth.ITMAX, opts.ctypes.data_as(D),
+                                 info.ctypes.data_as(D), ret.ctypes.data_as(C.POINTER(C.c_int)))
+    assert bad == int((ret < 0).sum())
+    for s in range(S):
+        r, p_ref, info_ref = L.brdf_fit("orc", 1, model, angles[s], x[s], synth.P0[model], synth.ITMAX, synth.OPTS, synth.LB, synth.UB)
+        if r >= 0 and ret[s] >= 0:
+            assert info[s, 1] <= info_ref[1] * (1 + 1e-3) + 1e-30
+    # zero measurement vector: the fit drives the model to zero (kd = ks = 0 is feasible)
+    flat = np.ascontiguousarray(angles[0].reshape(-1))
+    pz = np.array(synth.P0[model])
+    infoz = np.zeros(10)
+    rc = lib.dlevmar_bc_dif(C.cast(lib.BRDFFunc_hip, C.c_void_p), pz.ctypes.data_as(D), None, 3, n, lb.ctypes.data_as(D),
+                            ub.ctypes.data_as(D), None, synth.ITMAX, opts.ctypes.data_as(D), infoz.ctypes.data_as(D), None,
+                            None, C.byref(ExtraData(flat.ctypes.data_as(D), model)))
+    assert rc >= 0 and infoz[1] <= 1e-12 * infoz[0]
