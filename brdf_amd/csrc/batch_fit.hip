@@ -206,7 +206,7 @@ __global__ __launch_bounds__(THREADS, (batch_waves_per_simd<THREADS, SPT>())) vo
     }
     default: break;
     }
-    if (tid == 0) sm.step(sums, sums[kSums]);
+    if (tid == 0) sm.template step<true>(sums, sums[kSums]);
     __syncthreads();
   }
 

@@ -80,6 +80,20 @@ struct SumLayout {
   static constexpr int MAX = DIF_TRIAL > JAC ? DIF_TRIAL : JAC;
 };
 
+// On the device the LM step runs on ONE lane of a wave.  Values loaded from the LDS-resident machine are not
+// provably wave-uniform to the compiler, and a `switch` on such a value is lowered to exec-masked, structurised
+// control flow that walks every case with a compare + saveexec (~2000 cycles per step for the phase dispatch
+// alone, measured).  lm_uniform() tells the compiler the truth -- the value is the same in every active lane --
+// so the dispatch becomes scalar branches.  ONLY valid where a single lane steps (step<true>): the
+// four-fits-per-wave kernel steps four machines in four lanes at once and must not use it.
+LM_HD int lm_uniform(int v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_readfirstlane(v);
+#else
+  return v;
+#endif
+}
+
 LM_HD double lm_abs(double v) { return (v >= 0.0) ? v : -v; }
 LM_HD bool lm_finite(double v) { return (v - v) == 0.0; }  // false for NaN and +-Inf
 
@@ -338,11 +352,15 @@ struct DifMachine {
     }
   }
 
-  LM_HD void step(const double *s, double maxabs) { run(c, h, s, maxabs); }
+  // ONE_LANE: the caller guarantees that exactly one lane of the wave executes this step (see lm_uniform)
+  template <bool ONE_LANE = false>
+  LM_HD void step(const double *s, double maxabs) { run<ONE_LANE>(c, h, s, maxabs); }
 
+  template <bool ONE_LANE>
   static LM_HD void run(Cold &c, Hot &h, const double *s, double /*maxabs*/) {
-    int ph = h.phase;  // kept in a register: phase transitions become direct jumps, not LDS round trips
+    int ph = ONE_LANE ? lm_uniform(h.phase) : h.phase;  // scalar register: phase transitions become scalar jumps
     for (;;) {
+      if (ONE_LANE) ph = lm_uniform(ph);  // re-assert uniformity: assignments under (formally) divergent branches lose it
       switch (ph) {
       case D_INIT_EVAL:  // lm_core.c:551-564
         h.nfev = 1;
@@ -709,12 +727,15 @@ struct BcMachine {
     h.p_e2 = h.pdp_e2;
   }
 
-  LM_HD void step(const double *s, double maxabs) { run(c, h, s, maxabs); }
+  template <bool ONE_LANE = false>
+  LM_HD void step(const double *s, double maxabs) { run<ONE_LANE>(c, h, s, maxabs); }
 
+  template <bool ONE_LANE>
   static LM_HD void run(Cold &c, Hot &h, const double *s, double maxabs) {
     constexpr double alpha = 1e-4, beta = 0.9, gamma = 0.99995, rho = 1e-8, tming = 1e-18, tini = 1.0;
-    int ph = h.phase;  // kept in a register: phase transitions become direct jumps, not LDS round trips
+    int ph = ONE_LANE ? lm_uniform(h.phase) : h.phase;  // scalar register: phase transitions become scalar jumps
     for (;;) {
+      if (ONE_LANE) ph = lm_uniform(ph);  // re-assert uniformity: assignments under (formally) divergent branches lose it
       switch (ph) {
       case B_INIT_EVAL:  // lmbc_core.c:523-540
         h.nfev = 1;
@@ -1206,9 +1227,11 @@ struct DerMachine {
     h.phase = R_INIT_EVAL;
   }
 
+  template <bool ONE_LANE = false>
   LM_HD void step(const double *s, double /*maxabs*/) {
-    int ph = h.phase;
+    int ph = ONE_LANE ? lm_uniform(h.phase) : h.phase;
     for (;;) {
+      if (ONE_LANE) ph = lm_uniform(ph);  // re-assert uniformity: assignments under (formally) divergent branches lose it
       switch (ph) {
       case R_INIT_EVAL:  // lm_core.c:168-179
         h.nfev = 1;

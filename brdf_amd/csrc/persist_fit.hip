@@ -283,7 +283,7 @@ __global__ __launch_bounds__(kPThreads) void persist_fit_kernel(PersistCtx ctx) 
       default: block_reduce<1, kPThreads>(pv, pv[kSums], red, sums); break;
       }
       if (tid == 0) {
-        sm.step(sums, sums[kSums]);
+        sm.template step<true>(sums, sums[kSums]);
         rq.kind = sm.h.req.kind;
         rq.aux = sm.h.req.aux;
         rq.sel_hx = sm.h.req.sel_hx;

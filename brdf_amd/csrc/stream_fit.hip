@@ -115,7 +115,7 @@ __global__ __launch_bounds__(kStreamThreads, kStreamWavesPerSimd) void stream_pa
     const int kind_before_ = sm.h.req.kind, phase_before_ = sm.h.phase;
     const long long ts0_ = clock64();
 #endif
-    if (tid == 0) sm.step(sums, sums[kSums]);
+    if (tid == 0) sm.template step<true>(sums, sums[kSums]);
 #ifdef BRDF_STAMPS
     if (blockIdx.x == 0 && tid == 0 && pass < 4096) {
       ctx->dbg[pass * 4 + 0] = (int)(clock64() - ts0_);

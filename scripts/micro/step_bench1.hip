@@ -5,7 +5,7 @@
 using namespace brdf;
 
 template <int VARIANT>
-__global__ void step_kernel(long long *out, int *phases, int nsteps) {
+__global__ __attribute__((amdgpu_flat_work_group_size(1, 1))) void step_kernel(long long *out, int *phases, int nsteps) {
   __shared__ BcMachine<3> sm;
   __shared__ double sums[16];
   if (threadIdx.x == 0) {
@@ -26,7 +26,7 @@ __global__ void step_kernel(long long *out, int *phases, int nsteps) {
       }
       phases[it] = sm.h.phase * 1000 + kind;
       const long long t0 = clock64();
-      sm.template step<true>(sums, 1.0);
+      sm.step(sums, 1.0);
       out[it] = clock64() - t0;
     }
     __syncthreads();
@@ -39,7 +39,7 @@ int main() {
   long long *out; int *ph;
   hipMalloc(&out, N * 8); hipMalloc(&ph, N * 4);
   hipMemset(out, 0, N * 8); hipMemset(ph, 0, N * 4);
-  for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(step_kernel<0>, dim3(1), dim3(64), 0, 0, out, ph, N);
+  for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(step_kernel<0>, dim3(1), dim3(1), 0, 0, out, ph, N);
   hipDeviceSynchronize();
   static long long h[N]; static int p[N];
   hipMemcpy(h, out, N * 8, hipMemcpyDeviceToHost); hipMemcpy(p, ph, N * 4, hipMemcpyDeviceToHost);
