@@ -55,6 +55,7 @@ __global__ __launch_bounds__(THREADS, (batch_waves_per_simd<THREADS, SPT>())) vo
 
   const int fit = blockIdx.x;
   const int tid = threadIdx.x;
+  const bool first_wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x) < kWave;  // see stream_fit.hip
   const int n = ctx.n;
   if (!FAST && ctx.flags[fit] != kNeedsExact) return;  // exact kernel: only the fits the fast kernel declined
 
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(THREADS, (batch_waves_per_simd<THREADS, SPT>())) vo
   for (;;) {
     const int kind = sm.h.req.kind;
     if (kind == RQ_DONE) break;
-    if (tid == 0) su.build(sm.h.req);
+    if (first_wave) su.build(sm.h.req);
     __syncthreads();
     const PassUniforms<MODEL> &u = su;
     double acc[kSums];
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(THREADS, (batch_waves_per_simd<THREADS, SPT>())) vo
     }
     default: break;
     }
-    if (tid == 0) sm.template step<true>(sums, sums[kSums]);
+    if (first_wave) sm.template step<true>(sums, sums[kSums]);
     __syncthreads();
   }
 

@@ -103,6 +103,7 @@ __global__ __launch_bounds__(kPThreads) void persist_fit_kernel(PersistCtx ctx) 
   __shared__ int s_role;  // 1: this workgroup arrived last, 0: wait for the flag, -1: abort
 
   const int tid = threadIdx.x;
+  const bool first_wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x) < kWave;  // see stream_fit.hip
   const int G = gridDim.x;
   const int blk = blockIdx.x;
   const int n = ctx.n;
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(kPThreads) void persist_fit_kernel(PersistCtx ctx) 
       case RQ_DIF_TRIAL: block_reduce<SumLayout<kM>::DIF_TRIAL, kPThreads>(pv, pv[kSums], red, sums); break;
       default: block_reduce<1, kPThreads>(pv, pv[kSums], red, sums); break;
       }
-      if (tid == 0) {
+      if (first_wave) {
         sm.template step<true>(sums, sums[kSums]);
         rq.kind = sm.h.req.kind;
         rq.aux = sm.h.req.aux;

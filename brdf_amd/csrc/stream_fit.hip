@@ -70,6 +70,10 @@ __global__ __launch_bounds__(kStreamThreads, kStreamWavesPerSimd) void stream_pa
 
   const int tid = threadIdx.x;
   const int par = pass & 1;
+  // The scalar LM step is executed by the WHOLE first wave behind a wave-uniform branch (all 64 lanes compute and
+  // store identical values): inside a branch the compiler knows to be uniform, the step's own control flow is
+  // compiled to scalar branches; under `if (tid == 0)` it is structurised into exec-mask form and runs ~25 % slower.
+  const bool first_wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x) < kWave;
 #ifdef BRDF_STAMPS
   long long st_[8]; int sti_ = 0;
 #define STAMP() do { if (blockIdx.x == 0 && tid == 0) st_[sti_++] = clock64(); } while (0)
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(kStreamThreads, kStreamWavesPerSimd) void stream_pa
     const int kind_before_ = sm.h.req.kind, phase_before_ = sm.h.phase;
     const long long ts0_ = clock64();
 #endif
-    if (tid == 0) sm.template step<true>(sums, sums[kSums]);
+    if (first_wave) sm.template step<true>(sums, sums[kSums]);
 #ifdef BRDF_STAMPS
     if (blockIdx.x == 0 && tid == 0 && pass < 4096) {
       ctx->dbg[pass * 4 + 0] = (int)(clock64() - ts0_);
@@ -132,7 +136,7 @@ __global__ __launch_bounds__(kStreamThreads, kStreamWavesPerSimd) void stream_pa
     if (blockIdx.x == 0 && tid == 0) publish_result<METHOD>(ctx, sm, pass);
     return;
   }
-  if (tid == 0) su.build(sm.h.req);
+  if (first_wave) su.build(sm.h.req);
   STAMP();
   if (blockIdx.x == 0) {  // persist the advanced machine for the next launch
     const unsigned *src = reinterpret_cast<const unsigned *>(&sm);

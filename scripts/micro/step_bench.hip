@@ -16,7 +16,11 @@ __global__ void step_kernel(long long *out, int *phases, int nsteps) {
   }
   __syncthreads();
   for (int it = 0; it < nsteps; ++it) {
+#ifdef WHOLE_WAVE
+    {  // variant: the whole wave executes the step redundantly behind a wave-uniform branch
+#else
     if (threadIdx.x == 0) {
+#endif
       const int kind = sm.h.req.kind;
       if (kind == RQ_JAC) {  // a fixed SPD system
         sums[0] = 4.0; sums[1] = 1.0; sums[2] = 3.0; sums[3] = 0.5; sums[4] = 0.2; sums[5] = 2.0;
@@ -24,10 +28,11 @@ __global__ void step_kernel(long long *out, int *phases, int nsteps) {
       } else {
         sums[0] = (it == 0) ? 10.0 : 10.0 + 1e-3;  // never an improvement: line search, then projected gradient
       }
-      phases[it] = sm.h.phase * 1000 + kind;
+      if (threadIdx.x == 0) phases[it] = sm.h.phase * 1000 + kind;
       const long long t0 = clock64();
       sm.template step<true>(sums, 1.0);
-      out[it] = clock64() - t0;
+      const long long dt_ = clock64() - t0;
+      if (threadIdx.x == 0) out[it] = dt_;
     }
     __syncthreads();
     if (sm.h.req.kind == RQ_DONE) break;
