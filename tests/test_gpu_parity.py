@@ -451,3 +451,27 @@ def test_host_batch_entry_point_and_null_measurements(gpu):
                             ub.ctypes.data_as(D), None, synth.ITMAX, opts.ctypes.data_as(D), infoz.ctypes.data_as(D), None,
                             None, C.byref(ExtraData(flat.ctypes.data_as(D), model)))
     assert rc >= 0 and infoz[1] <= 1e-12 * infoz[0]
+
+
+def test_compiled_cpp_call_site_links_and_fits(gpu, tmp_path):
+    """tests/cpp/dropin_solve_equation.cpp: the reference's SolveEquation call site (its own struct extraData, its
+    own BRDFFunc, dlevmar_bc_dif with NULL work/covar) compiled by g++ and LINKED against libbrdf_hip.so in place
+    of liblevmar.a, plus the one registration line.  The application's callback must never run."""
+    import subprocess
+    exe = os.path.join(HERE, "cpp", "dropin_solve_equation")
+    subprocess.run(["make", "-s", "-C", os.path.join(HERE, "cpp"), "dropin_solve_equation"], check=True)
+    for model, n in ((1, 16), (1, 5000), (0, 2000)):
+        angles, x, _ = synth.make_single(model, n)
+        path = tmp_path / f"s{model}_{n}.bin"
+        np.concatenate([angles.reshape(-1), x]).tofile(path)
+        out = subprocess.run([exe, str(model), str(n), str(path)], capture_output=True, text=True, check=True).stdout
+        tok = next(l for l in out.splitlines() if l.startswith("RESULT")).split()
+        ret, calls = int(tok[1]), int(tok[2])
+        p = np.array([float.fromhex(t) for t in tok[3:6]])
+        info = np.array([float.fromhex(t) for t in tok[6:16]])
+        r, p_ref, info_ref = L.brdf_fit("orc", 1, model, angles, x, synth.P0[model], synth.ITMAX, synth.OPTS, synth.LB, synth.UB)
+        assert ret >= 0 and calls == 0
+        if n >= 64:
+            assert L.rel_err(p, p_ref) <= P_TOL and abs(info[1] - info_ref[1]) <= E_TOL * info_ref[1]
+        else:
+            assert info[1] <= info_ref[1] * (1 + 1e-6)
