@@ -29,6 +29,7 @@ struct BatchCtx {
   int *flags;            // [S] internal: kNeedsExact marks fits handed to the exact kernel
   int S, n, itmax;
   int has_opts, has_lb, has_ub;
+  int multi;  // bc_dif: projected-gradient candidates per sweep (workgroup/wave-per-fit kernels)
   double opts[5], lb[kM], ub[kM];
 };
 
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(THREADS, (batch_waves_per_simd<THREADS, SPT>())) vo
     if constexpr (METHOD == 0)
       sm.start(p0, n, ctx.itmax, opts, 0, /*speculative=*/0);
     else
-      sm.start(p0, n, ctx.has_lb ? ctx.lb : nullptr, ctx.has_ub ? ctx.ub : nullptr, nullptr, ctx.itmax, opts, 0);
+      sm.start(p0, n, ctx.has_lb ? ctx.lb : nullptr, ctx.has_ub ? ctx.ub : nullptr, nullptr, ctx.itmax, opts, 0, ctx.multi);
   }
   __syncthreads();
 
@@ -137,6 +138,21 @@ __global__ __launch_bounds__(THREADS, (batch_waves_per_simd<THREADS, SPT>())) vo
         mx = fmax(mx, fabs(e));
       }
       block_reduce<1, THREADS>(acc, mx, red, sums);
+      break;
+    case RQ_EVAL_MULTI:
+      if constexpr (THREADS < 512) {  // the 512 x 8 geometry never asks for it (see batch_fit_enqueue): keeping the
+                                       // unrolled 8 x 8 body out of that kernel keeps its samples in registers
+#pragma unroll
+        for (int k = 0; k < SPT; ++k) {
+#pragma unroll
+          for (int j = 0; j < kMaxCand; ++j)
+            if (j < u.ncand) {
+              const double e = ok[k] ? sx[k] - model_value_k<MODEL, FAST>(u, j, s0[k], pq[k]) : 0.0;
+              acc[j] += e * e;
+            }
+        }
+        block_reduce<kMaxCand, THREADS>(acc, mx, red, sums);
+      }
       break;
     case RQ_SCALED:
 #pragma unroll
@@ -598,6 +614,9 @@ int batch_fit_enqueue(const BatchFitArgs &a) {
   c.has_opts = a.opts != nullptr;
   c.has_lb = a.lb != nullptr;
   c.has_ub = a.ub != nullptr;
+  // projected-gradient candidates per sweep: pays where the LM step dominates a pass; the 512 x 8 geometry would
+  // spill its register-resident samples with 8 unrolled candidates (measured 2.4x slower), so it stays at one
+  c.multi = (g.threads == 512) ? 1 : pg_candidates();
   for (int i = 0; i < 5; ++i) c.opts[i] = a.opts ? a.opts[i] : 0.0;
   for (int i = 0; i < kM; ++i) {
     c.lb[i] = a.lb ? a.lb[i] : 0.0;

@@ -127,12 +127,24 @@ struct PassUniforms {
   double dinv[kM];  // 1/d_j (forward) or 0.5/d_j (central): misc_core.c:167, :206
   Lin lq;           // at q                       (dif trial)
   Nl nq;
+  Lin lk[kMaxCand];  // at the candidate points     (RQ_EVAL_MULTI)
+  Nl nk[kMaxCand];
   double dp[kM], dp_l2, scal;
-  int central;
+  int central, ncand;
 
   // only what the request kind reads is computed (each lin()/nl() hides an fp64 division or two, and on the
   // device this runs on a single lane between two passes)
   LM_HD void build(const Request<kM> &r) {
+    ncand = 0;
+    if (r.kind == RQ_EVAL_MULTI) {
+      ncand = r.nk;
+      for (int j = 0; j < kMaxCand; ++j)
+        if (j < r.nk) {
+          lk[j] = Mdl::lin(r.pk[j]);
+          nk[j] = Mdl::nl(r.pk[j]);
+        }
+      return;
+    }
     if (r.kind != RQ_DIF_UPDATE) {
       l0 = Mdl::lin(r.p);
       n0 = Mdl::nl(r.p);
@@ -166,6 +178,13 @@ template <int MODEL, bool FAST>
 LM_HD double model_value(const PassUniforms<MODEL> &u, double c0, const Prep &q) {
   using Mdl = BrdfModel<MODEL>;
   return Mdl::combine(u.l0, c0, Mdl::template shape<FAST>(u.n0, c0, q));
+}
+
+// f(pk[j]) for one sample (candidate j of a multi-candidate evaluation)
+template <int MODEL, bool FAST>
+LM_HD double model_value_k(const PassUniforms<MODEL> &u, int j, double c0, const Prep &q) {
+  using Mdl = BrdfModel<MODEL>;
+  return Mdl::combine(u.lk[j], c0, Mdl::template shape<FAST>(u.nk[j], c0, q));
 }
 
 // f(q) for one sample (dif trial point)

@@ -134,6 +134,7 @@ __host__ __device__ __forceinline__ int slots_of(int kind) {
   case RQ_DIF_JAC:
   case RQ_DIF_UPDATE: return SumLayout<kM>::DIF_JAC;
   case RQ_DIF_TRIAL: return SumLayout<kM>::DIF_TRIAL;
+  case RQ_EVAL_MULTI: return kMaxCand;
   default: return 0;
   }
 }

@@ -52,9 +52,13 @@ enum ReqKind : int {
   RQ_DIF_TRIAL = 6,  // speculative:  hx[!sel_hx] <- f(q); J[!sel_j] <- Broyden(J[sel_j]); sums = [sum e_new^2,
                      //   JnTJn lower, JnT e_new, JnT e_old]
                      // two-step:     wrk <- f(q); sums = [sum e_new^2]
-  RQ_DIF_UPDATE = 7  // two-step only: J <- Broyden(J, wrk, hx); sums = [JTJ lower, JT e] with e = x-wrk if
+  RQ_DIF_UPDATE = 7, // two-step only: J <- Broyden(J, wrk, hx); sums = [JTJ lower, JT e] with e = x-wrk if
                      //   aux (step accepted) else x-hx; finally hx <- wrk if aux
+  RQ_EVAL_MULTI = 8  // sums[j] = sum (x-f(pk[j]))^2 for j < nk: several candidates of a projected-gradient search
+                     //   in ONE sweep (the samples are read once; a pass's fixed cost is paid once)
 };
+
+constexpr int kMaxCand = 8;  // candidates per RQ_EVAL_MULTI
 
 template <int M>
 struct Request {
@@ -69,6 +73,9 @@ struct Request {
   double dp[M]; // Dp                                                 (RQ_DIF_TRIAL)
   double dp_l2; // ||Dp||^2
   double scal;  // RQ_SCALED divisor
+  int nk;       // RQ_EVAL_MULTI: number of candidate points
+  int pad_;
+  double pk[kMaxCand][M];
 };
 
 template <int M>
@@ -586,7 +593,7 @@ template <int M>
 struct BcMachine {
   enum Phase : int {
     B_INIT_EVAL = 1, B_ITER_TOP, B_AFTER_JAC, B_SOLVE, B_AFTER_LM_EVAL, B_AFTER_LM_NORM, B_LM_JUDGE,
-    B_LS_ISSUE, B_LS_EVAL, B_PG_BEGIN, B_PG_ISSUE, B_PG_EVAL, B_PG_NORM, B_PG_JUDGE, B_COMMIT,
+    B_LS_ISSUE, B_LS_EVAL, B_PG_BEGIN, B_PG_ISSUE, B_PG_EVAL, B_PG_NORM, B_PG_JUDGE, B_PG_MULTI, B_COMMIT,
     B_END_ITER, B_FINISH, B_DONE
   };
   struct Cold {  // configuration + results (see DifMachine for the Hot/Cold rationale)
@@ -596,6 +603,11 @@ struct BcMachine {
     double lb[M], ub[M], dscl[M];
     int infeasible_mask, bad_input;
     int analytic_jac;  // 1: dlevmar_bc_der (caller's Jacobian): no nfev correction at the end (lmbc_core.c:1119-1124)
+    int multi;         // candidates evaluated per pass in the projected-gradient search (1 = one at a time).  The
+                       // search of lmbc_core.c:885-935 tries t, 0.9t, 0.81t, ... along one fixed direction: the
+                       // next points are known before the current one has been judged, so K of them share a sweep.
+                       // Candidates are judged in the reference's order and only the judged ones count in nfev:
+                       // the trajectory and info[] are exactly those of the one-at-a-time search.
     double p_start[M];
     double info[kInfoSz], covar[M * M];
     int ret;
@@ -608,6 +620,7 @@ struct BcMachine {
     // line-search locals (lmbc_core.c:218-225)
     double ls_f0, ls_lambda, ls_plmbda, ls_pfpls, ls_tlmbda, ls_rmnlmb, ls_slp;
     int ls_first, ls_left;
+    int pg_n, pg_single;  // candidates in flight; force the next projected-gradient request to a single candidate
     Request<M> req;
   };
   Cold c;
@@ -658,7 +671,9 @@ struct BcMachine {
   }
 
   LM_HD void start(const double *p0, int n_, const double *lb_, const double *ub_, const double *dscl_,
-                   int itmax_, const double *opts, int want_covar_) {
+                   int itmax_, const double *opts, int want_covar_, int multi_ = 1) {
+    c.multi = (multi_ < 1) ? 1 : ((multi_ > kMaxCand) ? kMaxCand : multi_);
+    h.pg_n = h.pg_single = 0;
     c.o = make_options(opts);
     if (opts) {  // bc_dif reads delta as |opts[4]| and the sign as the FD flavour: lmbc_core.c:1105,1115
       c.o.forward = (opts[4] >= 0.0);
@@ -1038,23 +1053,98 @@ struct BcMachine {
           ph = B_END_ITER;
           break;
         }
-        const double tt = h.t;
-        double pc[M], v[M], l2 = 0.0;
+        double pc[M], g[M];
         for (int i = 0; i < M; ++i) {
           pc[i] = h.p[i];
-          v[i] = pc[i] - tt * h.jte[i];
+          g[i] = h.jte[i];
         }
-        project(c, v);
-        for (int i = 0; i < M; ++i) {
-          const double d = v[i] - pc[i];
-          h.pdp[i] = v[i];
-          h.dp[i] = d;
-          l2 += d * d;
+        const int want = h.pg_single ? 1 : c.multi;
+        h.pg_single = 0;
+        double tt = h.t;
+        int cnt = 0;
+        double v0[M];
+        for (int j = 0; j < kMaxCand; ++j) {  // t, t*beta, t*beta^2, ... exactly as the loop increment forms them
+          if (j >= want || !(tt > tming)) break;
+          double v[M];
+          for (int i = 0; i < M; ++i) v[i] = pc[i] - tt * g[i];
+          project(c, v);
+          for (int i = 0; i < M; ++i) {
+            if (j == 0) v0[i] = v[i];
+            h.req.pk[j][i] = c.has_dscl ? v[i] * c.dscl[i] : v[i];
+          }
+          ++cnt;
+          tt *= beta;
         }
-        h.dp_l2 = l2;
-        request_eval(c, h, v);
-        ph = B_PG_EVAL;
+        if (cnt <= 1) {  // one candidate: the plain evaluation request
+          double l2 = 0.0;
+          for (int i = 0; i < M; ++i) {
+            const double d = v0[i] - pc[i];
+            h.pdp[i] = v0[i];
+            h.dp[i] = d;
+            l2 += d * d;
+          }
+          h.dp_l2 = l2;
+          request_eval(c, h, v0);
+          ph = B_PG_EVAL;
+          { h.phase = ph; return; }
+        }
+        h.pg_n = cnt;
+        h.req.kind = RQ_EVAL_MULTI;
+        h.req.nk = cnt;
+        h.req.scal = 1.0;
+        ph = B_PG_MULTI;
         { h.phase = ph; return; }
+      }
+
+      case B_PG_MULTI: {  // judge the candidates of one sweep in the reference's order (lmbc_core.c:886-935)
+        double pc[M], g[M];
+        for (int i = 0; i < M; ++i) {
+          pc[i] = h.p[i];
+          g[i] = h.jte[i];
+        }
+        const double fold = h.p_e2;
+        const int cnt = h.pg_n;
+        double tt = h.t;
+        int next = B_PG_ISSUE;
+        for (int j = 0; j < kMaxCand; ++j) {
+          if (j >= cnt) break;
+          double v[M], d[M], l2 = 0.0, gd = 0.0;
+          for (int i = 0; i < M; ++i) v[i] = pc[i] - tt * g[i];
+          project(c, v);
+          for (int i = 0; i < M; ++i) {
+            d[i] = v[i] - pc[i];
+            l2 += d[i] * d[i];
+          }
+          const double fnew = s[j];
+          if (!lm_finite(fnew)) {  // overflow guard needs max|e| of this candidate: evaluate it alone
+            h.pg_single = 1;
+            break;
+          }
+          ++h.nfev;
+          for (int i = 0; i < M; ++i) {
+            h.pdp[i] = v[i];
+            h.dp[i] = d[i];
+            gd += g[i] * d[i];
+          }
+          h.dp_l2 = l2;
+          h.pdp_e2 = fnew;
+          h.gdp = gd;
+          if (h.gprev && fnew <= fold + 2.0 * 0.99999 * gd) {  // remembered t was too small
+            tt = h.t0;
+            h.gprev = 0;
+            tt *= beta;
+            break;
+          }
+          if (fnew <= fold + 2.0 * alpha * gd) {
+            h.gprev = 1;
+            next = B_COMMIT;
+            break;
+          }
+          tt *= beta;
+        }
+        h.t = tt;
+        ph = next;
+        break;
       }
 
       case B_PG_EVAL:

@@ -82,6 +82,7 @@ bool persist_fit_try(const StreamFitArgs &a, int *ret);
 FitStats persist_fit_last_stats();
 
 bool brdf_fast_path_enabled();  // false when BRDF_HIP_EXACT_POW=1
+int pg_candidates();            // BRDF_HIP_PG_MULTI (default kMaxCand)
 void set_error(const char *fmt, ...);
 const char *get_error();
 

@@ -112,6 +112,7 @@ __global__ __launch_bounds__(kStreamThreads, kStreamWavesPerSimd) void stream_pa
     case RQ_JAC: block_reduce<SumLayout<kM>::JAC, kStreamThreads>(pv, pv[kSums], red, sums); break;
     case RQ_DIF_JAC: block_reduce<SumLayout<kM>::DIF_JAC, kStreamThreads>(pv, pv[kSums], red, sums); break;
     case RQ_DIF_TRIAL: block_reduce<SumLayout<kM>::DIF_TRIAL, kStreamThreads>(pv, pv[kSums], red, sums); break;
+    case RQ_EVAL_MULTI: block_reduce<kMaxCand, kStreamThreads>(pv, pv[kSums], red, sums); break;
     default: block_reduce<1, kStreamThreads>(pv, pv[kSums], red, sums); break;
     }
     STAMP();
@@ -229,6 +230,21 @@ __global__ __launch_bounds__(kStreamThreads, kStreamWavesPerSimd) void stream_pa
     SWEEP_END
     STAMP();
     block_reduce<1, kStreamThreads>(acc, mx, red, sums);
+    break;
+  case RQ_EVAL_MULTI:  // several projected-gradient candidates share one sweep (lm_machine.h, BcMachine::Cold::multi)
+    SWEEP_BEGIN(4)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+      for (int j = 0; j < kMaxCand; ++j)
+        if (j < u.ncand) {
+          const double e = ok[k] ? sx[k] - model_value_k<MODEL, FAST>(u, j, s0[k], pq[k]) : 0.0;
+          acc[j] += e * e;
+        }
+    }
+    SWEEP_END
+    STAMP();
+    block_reduce<kMaxCand, kStreamThreads>(acc, mx, red, sums);
     break;
   case RQ_SCALED:
     SWEEP_BEGIN(4)
@@ -457,6 +473,7 @@ int blocks_for(int n) {
 static thread_local bool g_last_was_persistent = false;
 FitStats stream_fit_last_stats() { return g_last_was_persistent ? persist_fit_last_stats() : g_ws.stats; }
 bool brdf_fast_path_enabled();
+int pg_candidates();
 
 // one attempt on the FAST (prepared-sample) or the exact model path; *retry_exact is set when the FAST path
 // met a cosine <= 0 and the result must be discarded
@@ -493,7 +510,7 @@ static int stream_fit_attempt(const StreamFitArgs &a, bool fast, bool *retry_exa
     }
   } else {
     BcMachine<kM> &m = h.m[0].bc;
-    m.start(a.p, a.n, a.lb, a.ub, a.dscl, a.itmax, a.opts, a.covar != nullptr);
+    m.start(a.p, a.n, a.lb, a.ub, a.dscl, a.itmax, a.opts, a.covar != nullptr, pg_candidates());
     if (m.h.req.kind == RQ_DONE) {
       switch (m.c.bad_input) {
       case 1: set_error("dlevmar_bc_dif(): cannot solve a problem with fewer measurements [%d] than unknowns [%d]", a.n, kM); break;
@@ -570,6 +587,13 @@ static int stream_fit_attempt(const StreamFitArgs &a, bool fast, bool *retry_exa
   }
 #endif
   return mb.ret;
+}
+
+// BRDF_HIP_PG_MULTI=k: candidates per sweep in bc_dif's projected-gradient search (default 8, 1 = one at a time)
+int pg_candidates() {
+  const char *e = getenv("BRDF_HIP_PG_MULTI");
+  const int k = e ? atoi(e) : kMaxCand;
+  return k < 1 ? 1 : (k > kMaxCand ? kMaxCand : k);
 }
 
 // BRDF_HIP_EXACT_POW=1 forces the exact model path (reference expression, pow per evaluation)

@@ -18,6 +18,7 @@ using namespace brdf;
 namespace {
 
 int g_speculative = 1;  // dif protocol under test (see lm_machine.h)
+int g_multi = 1;        // bc: candidates per projected-gradient sweep
 
 template <int MODEL, bool FAST>
 struct HostPasses {
@@ -62,6 +63,13 @@ struct HostPasses {
           acc += t * t;
         }
         s[0] = acc;
+      }
+      break;
+    }
+    case RQ_EVAL_MULTI: {
+      for (int j = 0; j < r.nk; ++j) {
+        for (int i = 0; i < n; ++i) f[i] = model_value_k<MODEL, FAST>(u, j, c0[i], prep(i));
+        s[j] = orc_l2_residual(e.data(), x, f.data(), n);
       }
       break;
     }
@@ -165,7 +173,7 @@ int fit(int method, double *angles, double *x, int n, double *p, int itmax, doub
   }
   HostPasses<MODEL, FAST> hp(angles, x, n, 1);
   BcMachine<3> m;
-  m.start(p, n, lb, ub, dscl, itmax, opts, covar != nullptr);
+  m.start(p, n, lb, ub, dscl, itmax, opts, covar != nullptr, g_multi);
   while (m.h.req.kind != RQ_DONE) {
     hp.run(m.h.req, s, mx);
     ++np;
@@ -204,3 +212,4 @@ extern "C" int hm_brdf_fit_fast(int method, int model, double *angles, double *x
 }
 
 extern "C" void hm_set_dif_protocol(int speculative) { g_speculative = speculative; }
+extern "C" void hm_set_bc_multi(int k) { g_multi = k; }

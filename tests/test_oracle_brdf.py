@@ -139,3 +139,21 @@ def test_two_step_dif_protocol_is_bit_exact_too():
             assert r == f["ret"] and np.array_equal(p, _hex(f["p"])) and np.array_equal(info, _hex(f["info"]))
     finally:
         L.hm.hm_set_dif_protocol(1)
+
+
+@pytest.mark.parametrize("k", [2, 5, 8])
+def test_multi_candidate_projected_gradient_is_bit_exact(k):
+    """bc_dif's projected-gradient search evaluated k candidates per sweep (BcMachine::Cold::multi): candidates are
+    judged in the reference's order and only the judged ones are counted, so p, info[] (nfev included) are exactly
+    the reference's -- for every fixture"""
+    L.hm.hm_set_bc_multi(k)
+    try:
+        for f in FITS:
+            if f["method"] != 1:
+                continue
+            angles, x, _ = synth.make_single(f["model"], f["n"])
+            r, p, info = L.brdf_fit("hm", 1, f["model"], angles, x, synth.P0[f["model"]], synth.ITMAX, synth.OPTS,
+                                    synth.LB, synth.UB)
+            assert r == f["ret"] and np.array_equal(p, _hex(f["p"])) and np.array_equal(info, _hex(f["info"]))
+    finally:
+        L.hm.hm_set_bc_multi(1)
