@@ -98,7 +98,7 @@ def main():
         for _ in range(warmup):
             brdf_amd.fit_single(method, MODEL, a_dev, x_dev, p0, lb=lb, ub=ub, itmax=itmax, opts=opts)
         results = torch.zeros((steps, 13), dtype=torch.float64)
-        passes = jac = 0
+        passes = jac = launches = 0
         dev_us = 0.0
         if world > 1:
             dist.barrier()
@@ -114,6 +114,7 @@ def main():
             results[s, 3:] = torch.from_numpy(r.info)
             st = brdf_amd.last_fit_stats()
             passes += st["passes"]
+            launches += st["launches"]
             jac += st["jac_passes"]
             dev_us += st["device_us"]
         ev1.record()
@@ -126,7 +127,8 @@ def main():
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
         ev_ms = ev0.elapsed_time(ev1)
-        stat = torch.tensor([wall, float(results[:, 10].sum().item()) * N_SAMPLES, ev_ms, float(passes), float(jac), dev_us],
+        stat = torch.tensor([wall, float(results[:, 10].sum().item()) * N_SAMPLES, ev_ms, float(passes), float(jac), dev_us,
+                             float(launches)],
                             dtype=torch.float64, device=coll_dev)
         if world > 1:
             allstat = [torch.empty_like(stat) for _ in range(world)]
@@ -151,7 +153,12 @@ def main():
             "nfev": float(r0[0, 10]), "iters": float(r0[0, 8]), "passes_per_step": float(allstat[0, 3]) / args.steps,
             "event_ms_rank0": float(allstat[0, 2]), "device_us_per_step": float(allstat[0, 5]) / args.steps,
             "p": [float(v) for v in r0[0, :3]], "sumsq": float(r0[0, 4]),
-            "avg_launch_us": 1e3 * float(allstat[0, 2]) / max(1.0, float(allstat[0, 3])),
+            # HIP-event time of the timed region / ALL launches of the pass kernel in it (the passes plus the few
+            # run-ahead launches per fit that find it finished): the population rocprofv3 averages over
+            "avg_launch_us": 1e3 * float(allstat[0, 2]) / max(1.0, float(allstat[0, 6])),
+            "launches_per_step": float(allstat[0, 6]) / args.steps,
+            # device clock (s_memrealtime) from the first to the finishing pass / passes: sweeping launches only
+            "avg_sweeping_launch_us": float(allstat[0, 5]) / max(1.0, float(allstat[0, 3])),
         }
 
     if rank != 0:
@@ -177,20 +184,23 @@ def main():
         "config": {"workload": "BASELINE.json configs[1]: single-material Ward 3-param fit, 1,000,000 synthetic samples, "
                                "dlevmar_dif (FD Jacobian + Broyden), p0={0.5,0.5,0.3}, opts={1e-3,1e-15,1e-15,1e-20,1e-6}, itmax=100; "
                                "one step = one complete fit, samples resident in HBM; one material per GPU",
-                   "n_samples": N_SAMPLES, "model": "ward", "entry_point": "dlevmar_dif", "fits_per_step_per_gpu": 1,
+                   "n_samples": N_SAMPLES, "brdf": "ward", "entry_point": "dlevmar_dif", "fits_per_step_per_gpu": 1,
                    "nfev_per_fit": head["nfev"], "lm_iterations": head["iters"], "passes_per_fit": head["passes_per_step"]},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic,
                      "kernel": "brdf::stream_pass<2,0,true> (fused model eval + residual + Broyden + JtJ/Jte sweep, one launch per LM evaluation)",
                      "algorithmic_bytes_per_launch": bytes_per_launch,
-                     "avg_launch_us": head["avg_launch_us"],
-                     "note": "avg launch = HIP-event time of the timed region / pass launches in it (includes inter-launch gaps and the "
-                             "in-kernel LM state-machine step); 32 B per sample-pass for Ward (3 planes + measurement, fp64); traffic = "
+                     "avg_launch_us": head["avg_launch_us"], "avg_sweeping_launch_us": head["avg_sweeping_launch_us"],
+                     "launches_per_step": head["launches_per_step"],
+                     "note": "avg launch = HIP-event time of the timed region / launches of the pass kernel in it (passes + run-ahead "
+                             "launches that return at once; includes inter-launch gaps, the per-fit upload and the in-kernel LM step); "
+                             "avg_sweeping_launch_us = device clock over the passes only; 32 B per sample-pass for Ward (3 planes + measurement, fp64); traffic = "
                              "HBM-side bytes per launch from rocprofv3 FETCH_SIZE (x2 gfx950 correction, calibrated) + WRITE_SIZE, "
                              "profiles/r01_traffic.json: the dif trial pass really moves 96 B/sample (secant Jacobian and hx are "
                              "read and rewritten), the bc_dif pass moves exactly the algorithmic 32 B/sample"},
         "fitted_params": head["p"], "sumsq": head["sumsq"],
-        "bc_dif": {k: out["bc_dif"][k] for k in ("value", "ms_per_step", "nfev", "iters", "passes_per_step", "avg_launch_us", "p")},
+        "bc_dif": {k: out["bc_dif"][k] for k in ("value", "ms_per_step", "nfev", "iters", "passes_per_step", "launches_per_step", "avg_launch_us",
+                                                    "avg_sweeping_launch_us", "p")},
     }
     if not args.no_cpu:
         base, p_cpu, info_cpu = cpu_baseline(0, angles, x, p0, opts, lb, ub, itmax)

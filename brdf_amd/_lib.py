@@ -43,6 +43,7 @@ ABI = {
                                      C.c_void_p, C.c_void_p]),
     "brdf_hip_device_count": (C.c_int, []),
     "brdf_hip_last_error": (C.c_char_p, []),
+    "brdf_hip_last_fit_launches": (C.c_longlong, []),
     "brdf_hip_last_fit_stamps": (C.c_int, [C.POINTER(C.c_longlong)]),
     "brdf_hip_last_fit_stats": (C.c_int, [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong),
                                           D]),

@@ -325,6 +325,8 @@ int brdf_hip_last_fit_stats(long long *passes, long long *jac_passes, long long 
   return 0;
 }
 
+long long brdf_hip_last_fit_launches(void) { return stream_fit_last_stats().launches; }
+
 /* diagnostic builds (-DBRDF_STAMPS) only: cycles per section of the pass kernel, summed over passes */
 int brdf_hip_last_fit_stamps(long long *out8) {
   const FitStats s = stream_fit_last_stats();

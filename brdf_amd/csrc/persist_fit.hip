@@ -470,6 +470,7 @@ int persist_attempt(const StreamFitArgs &a, PWorkspace &ws, bool *retry_exact, b
   if (a.covar)
     for (int i = 0; i < kM * kM; ++i) a.covar[i] = mb.covar[i];
   ws.stats.passes = mb.passes;
+  ws.stats.launches = 1;
   ws.stats.jac_passes = (long long)mb.info[8];
   ws.stats.eval_passes = mb.passes - ws.stats.jac_passes;
   ws.stats.device_us = 1e3 * ms;

@@ -72,6 +72,7 @@ int stream_fit_run(const StreamFitArgs &a);
 
 struct FitStats {
   long long passes, jac_passes, eval_passes;
+  long long launches;  // kernel launches enqueued for the fit, run-ahead launches that found it finished included
   double device_us;
   long long stamps[8];
 };

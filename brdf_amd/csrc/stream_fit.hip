@@ -571,6 +571,7 @@ static int stream_fit_attempt(const StreamFitArgs &a, bool fast, bool *retry_exa
   if (a.covar)
     for (int i = 0; i < kM * kM; ++i) a.covar[i] = mb.covar[i];
   ws.stats.passes = mb.passes;
+  ws.stats.launches = pass;
   ws.stats.jac_passes = mb.n_jac;
   ws.stats.eval_passes = mb.n_eval;
   ws.stats.device_us = (double)(mb.t_last - mb.t_first) / 100.0;  // s_memrealtime ticks at 100 MHz

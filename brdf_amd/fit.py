@@ -123,4 +123,5 @@ def last_fit_stats() -> dict:
     a, b, c = C.c_longlong(0), C.c_longlong(0), C.c_longlong(0)
     us = C.c_double(0.0)
     lib.brdf_hip_last_fit_stats(C.byref(a), C.byref(b), C.byref(c), C.byref(us))
-    return {"passes": a.value, "jac_passes": b.value, "eval_passes": c.value, "device_us": us.value}
+    return {"passes": a.value, "jac_passes": b.value, "eval_passes": c.value, "device_us": us.value,
+            "launches": lib.brdf_hip_last_fit_launches()}

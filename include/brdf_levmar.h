@@ -135,6 +135,10 @@ const char *brdf_hip_last_error(void);
 int brdf_hip_last_fit_stats(long long *passes, long long *jac_passes, long long *eval_passes,
                             double *device_us);
 
+/* kernel launches the most recent brdf_hip_fit_dev enqueued (its passes + the few run-ahead launches that found
+ * the fit finished and returned at once): the population a profiler averages a kernel's duration over. */
+long long brdf_hip_last_fit_launches(void);
+
 /* only meaningful in diagnostic builds (-DBRDF_STAMPS): shader cycles spent per section of the pass
  * kernel (load state, fold, step, uniforms, persist, sweep, reduce), summed over the fit's passes. */
 int brdf_hip_last_fit_stamps(long long *out8);
