@@ -178,7 +178,7 @@ def main():
     bytes_per_launch = BYTES_PER_SAMPLE_PASS[MODEL] * N_SAMPLES
     achieved = bytes_per_launch / (head["avg_launch_us"] * 1e-6) / 1e9
     line = {
-        "metric": "BRDF residual-evals/sec (whole job)", "value": head["value"], "unit": "residual-evals/s",
+        "metric": "BRDF residual-evals/sec (1 M samples, Ward 3-param), whole job; rel-err vs CPU levmar in `parity`", "value": head["value"], "unit": "residual-evals/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "BASELINE.json configs[1]: single-material Ward 3-param fit, 1,000,000 synthetic samples, "

@@ -475,3 +475,19 @@ def test_compiled_cpp_call_site_links_and_fits(gpu, tmp_path):
             assert L.rel_err(p, p_ref) <= P_TOL and abs(info[1] - info_ref[1]) <= E_TOL * info_ref[1]
         else:
             assert info[1] <= info_ref[1] * (1 + 1e-6)
+
+
+@pytest.mark.parametrize("n", [16 * 2500, 16 * 25183])
+def test_single_brdf_call_site_configuration(gpu, n):
+    """CBRDFdata::SolveEquation_SingleBRDF (brdfdata.cpp:991-1075): ONE fit over all faces x 16 lights with
+    p0 = {0,0,0}, itmax = 2000 and opts = {1e-3, 1e-15, 1e-10, 1e-50, delta = 1} (brdfdata.cpp:1002, :1048, :1055-1056),
+    bounds [0,100]^3, through dlevmar_bc_dif.  16 x 25,183 = 402,928 is the bunny mesh's face count."""
+    model = 1
+    angles, x, _ = synth.make_single(model, n)
+    p0 = (0.0, 0.0, 0.0)
+    opts = (1e-3, 1e-15, 1e-10, 1e-50, 1.0)
+    r, p_ref, info_ref = L.brdf_fit("orc", 1, model, angles, x, p0, 2000, opts, synth.LB, synth.UB)
+    res = _dev_fit(gpu, 1, model, angles, x, p0=p0, itmax=2000, opts=opts)
+    assert r >= 0 and res.ret >= 0
+    assert L.rel_err(res.p, p_ref) <= P_TOL, (res.p, p_ref)
+    assert abs(res.info[1] - info_ref[1]) <= E_TOL * info_ref[1]
