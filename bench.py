@@ -249,37 +249,53 @@ def main():
         return
 
     head = out["dif"]
+    # The dominant kernel.  Resident regime (default for dlevmar_dif when the fit fits the chip): ONE launch per fit, the
+    # launch performs passes_per_fit sweeps over samples it read from HBM once.  Launch chain: one launch per sweep.
+    resident = head["launches_per_step"] < 1.5
+    kernel = "resident_fit_kernel<2, 0, true>" if resident else "stream_pass<2, 0, true>"
     # HBM traffic per launch: measured with rocprofv3 PMC counters in separate profiling passes of this very
     # command (scripts/profile_round.sh), corrected as MI355X_MICROARCH.md prescribes; committed under profiles/
     traffic = None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-        traffic = tj["kernels"]["stream_pass<2, 0, true>"]["hbm_bytes_per_launch"]
+        traffic = tj["kernels"][kernel]["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
-    bytes_per_launch = BYTES_PER_SAMPLE_PASS[MODEL] * N_SAMPLES
+    sweeps_per_launch = head["passes_per_step"] if resident else 1.0
+    bytes_per_launch = BYTES_PER_SAMPLE_PASS[MODEL] * N_SAMPLES * sweeps_per_launch
     achieved = bytes_per_launch / (head["avg_launch_us"] * 1e-6) / 1e9
+    if resident:
+        kernel_desc = ("brdf::resident_fit_kernel<2,0,true> (one launch per fit: samples + secant Jacobian resident in registers/LDS, "
+                       "model eval + residual + Broyden + JtJ/Jte fused per LM evaluation, in-launch all-gather between evaluations)")
+        note = ("algorithmic bytes = 32 B per sample per LM evaluation (Ward: 3 planes + measurement, fp64) x 1e6 samples x the "
+                "launch's evaluations (sweeps_per_launch); avg launch = HIP-event time of the timed region / launches (= fits; "
+                "includes the per-fit upload, the in-launch exchanges and the serial LM steps); avg_sweeping_launch_us = device clock "
+                "per evaluation.  traffic = HBM-side bytes per launch from rocprofv3 FETCH_SIZE (x2 gfx950 correction, calibrated) + "
+                "WRITE_SIZE, profiles/r01_traffic.json: the samples are read ONCE per fit, so the measured traffic is ~1/sweeps of the "
+                "algorithmic bytes -- the launch is bound by the exchange + LM step latency and fp64 issue, not by HBM (DESIGN.md)")
+    else:
+        kernel_desc = "brdf::stream_pass<2,0,true> (fused model eval + residual + Broyden + JtJ/Jte sweep, one launch per LM evaluation)"
+        note = ("avg launch = HIP-event time of the timed region / launches of the pass kernel in it (passes + run-ahead "
+                "launches that return at once; includes inter-launch gaps, the per-fit upload and the in-kernel LM step); "
+                "avg_sweeping_launch_us = device clock over the passes only; 32 B per sample-pass for Ward (3 planes + measurement, fp64); traffic = "
+                "HBM-side bytes per launch from rocprofv3 FETCH_SIZE (x2 gfx950 correction, calibrated) + WRITE_SIZE, "
+                "profiles/r01_traffic.json: the dif trial pass really moves 80 B/sample (the secant Jacobian is "
+                "read and rewritten), the bc_dif pass moves exactly the algorithmic 32 B/sample")
     line = {
         "metric": "BRDF residual-evals/sec (1 M samples, Ward 3-param), whole job; rel-err vs CPU levmar in `parity`", "value": head["value"], "unit": "residual-evals/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "BASELINE.json configs[1]: single-material Ward 3-param fit, 1,000,000 synthetic samples, "
                                "dlevmar_dif (FD Jacobian + Broyden), p0={0.5,0.5,0.3}, opts={1e-3,1e-15,1e-15,1e-20,1e-6}, itmax=100; "
-                               "one step = one complete fit, samples resident in HBM; one material per GPU",
+                               "one step = one complete fit, samples resident in HBM when the timed region starts; one material per GPU",
                    "n_samples": N_SAMPLES, "brdf": "ward", "entry_point": "dlevmar_dif", "fits_per_step_per_gpu": 1,
                    "nfev_per_fit": head["nfev"], "lm_iterations": head["iters"], "passes_per_fit": head["passes_per_step"]},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic,
-                     "kernel": "brdf::stream_pass<2,0,true> (fused model eval + residual + Broyden + JtJ/Jte sweep, one launch per LM evaluation)",
-                     "algorithmic_bytes_per_launch": bytes_per_launch,
+                     "kernel": kernel_desc, "regime": "resident" if resident else "launch chain",
+                     "algorithmic_bytes_per_launch": bytes_per_launch, "sweeps_per_launch": sweeps_per_launch,
                      "avg_launch_us": head["avg_launch_us"], "avg_sweeping_launch_us": head["avg_sweeping_launch_us"],
-                     "launches_per_step": head["launches_per_step"],
-                     "note": "avg launch = HIP-event time of the timed region / launches of the pass kernel in it (passes + run-ahead "
-                             "launches that return at once; includes inter-launch gaps, the per-fit upload and the in-kernel LM step); "
-                             "avg_sweeping_launch_us = device clock over the passes only; 32 B per sample-pass for Ward (3 planes + measurement, fp64); traffic = "
-                             "HBM-side bytes per launch from rocprofv3 FETCH_SIZE (x2 gfx950 correction, calibrated) + WRITE_SIZE, "
-                             "profiles/r01_traffic.json: the dif trial pass really moves 96 B/sample (secant Jacobian and hx are "
-                             "read and rewritten), the bc_dif pass moves exactly the algorithmic 32 B/sample"},
+                     "launches_per_step": head["launches_per_step"], "note": note},
         "fitted_params": head["p"], "sumsq": head["sumsq"],
         "bc_dif": {k: out["bc_dif"][k] for k in ("value", "ms_per_step", "nfev", "iters", "passes_per_step", "launches_per_step", "avg_launch_us",
                                                     "avg_sweeping_launch_us", "p")},

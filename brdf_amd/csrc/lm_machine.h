@@ -37,6 +37,10 @@ constexpr double kOneThird = 0.3333333334;
 constexpr int kLsItMax = 150;
 constexpr double kLsPow = 2.1;
 constexpr double kInitMu = 1E-03;
+#ifndef LM_STAMP
+#define LM_STAMP(i) do {} while (0)  // diagnostic builds (-DBRDF_STAMPS) time the sections of a step
+#endif
+
 constexpr double kStopThresh = 1E-17;
 constexpr double kDiffDelta = 1E-06;
 constexpr int kInfoSz = 10;
@@ -366,6 +370,7 @@ struct DifMachine {
   template <bool ONE_LANE>
   static LM_HD void run(Cold &c, Hot &h, const double *s, double /*maxabs*/) {
     int ph = ONE_LANE ? lm_uniform(h.phase) : h.phase;  // scalar register: phase transitions become scalar jumps
+    LM_STAMP(0);
     for (;;) {
       if (ONE_LANE) ph = lm_uniform(ph);  // re-assert uniformity: assignments under (formally) divergent branches lose it
       switch (ph) {
@@ -425,6 +430,7 @@ struct DifMachine {
         break;
 
       case D_SOLVE: {
+        LM_STAMP(2);
         if (h.jte_inf <= c.o.eps1) {  // lm_core.c:676-680
           h.dp_l2 = 0.0;
           h.stop = 1;
@@ -439,6 +445,7 @@ struct DifMachine {
         }
         for (int i = 0; i < M; ++i) h.jtj[i * M + i] += h.mu;
         const int solved = lu_solve<M>(h.jtj, h.jte, h.dp);
+        LM_STAMP(3);
         ++h.nlss;
         if (!solved) {
           ph = D_REJECT;
@@ -470,6 +477,7 @@ struct DifMachine {
         h.req.dp_l2 = h.dp_l2;
         ++h.nfev;
         ph = D_AFTER_TRIAL;
+        LM_STAMP(4);
         { h.phase = ph; return; }
       }
 
@@ -514,6 +522,7 @@ struct DifMachine {
             { h.phase = ph; return; }
           }
         }
+        LM_STAMP(1);
         ph = D_DECIDE;
         break;
       }

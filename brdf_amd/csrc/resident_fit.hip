@@ -1,0 +1,652 @@
+// resident_fit.hip -- "resident" regime: ONE launch per fit, the samples never leave the chip.
+//
+// For fits that fit the chip's register file + LDS (n <= #CUs * 4096 samples, i.e. 1,048,576 on MI355X) the whole
+// fit runs inside one launch of #CUs workgroups (one per CU, all co-resident).  Every workgroup reads its tile of
+// the sample planes from HBM exactly once and keeps it for the rest of the fit:
+//
+//   registers (per lane, 8 samples)   c0, x, the two per-sample invariants (brdf_models.h: Prep) and, for
+//                                     dlevmar_dif, f(p) and f(p+Dp)                      (lm_core.c:551, :742)
+//   LDS (dlevmar_dif only, 128 KiB)   the secant Jacobian rows (3 planes) and the pending Broyden coefficient
+//                                                                                         (lm_core.c:759-769)
+//
+// A pass (= one LM evaluation: e=x-hx / ||e||^2, FD Jacobian, J^T J / J^T e, Broyden update, brdfdata.cpp:975-988 +
+// misc_core.c:153-171 + lm_core.c:617-653) therefore moves no sample bytes at all.  Passes are separated by an
+// in-launch ALL-GATHER of the per-workgroup partial sums instead of a kernel boundary:
+//
+//   every workgroup : sweep -> workgroup reduction -> its <=14 partial sums as tagged 8-byte granules
+//                     {epoch tag : 32, half of the double : 32}, each ONE write-through (sc1) store
+//   every workgroup : thread r re-reads row r's granules (L1-bypassing loads) until every tag equals the epoch,
+//                     then all rows are folded in a fixed order and the workgroup steps ITS OWN copy of the LM
+//                     state machine (lm_machine.h) -- the same redundant execution as the launch chain of
+//                     stream_fit.hip, so there is no second hop (no ticket, no "last arriver", no broadcast)
+//
+// This is recipe R2 of the CDNA guide (cdna_hip_programming.md, Guideline 16: "the data IS the flag"): a granule is
+// one naturally aligned 8-byte word written by one store, so it cannot tear; no flag, no fence, no ordering between
+// granules is needed.  The rows are double-buffered by epoch parity: a workgroup can be at most one epoch ahead of
+// the slowest one (it needs everybody's row of epoch e+1 before it can publish epoch e+2), so two buffers suffice.
+// Results do not depend on dispatch order or XCD placement (fold order = workgroup index).  Every spin is bounded by
+// a wall-clock budget: if the grid is not co-resident (or anything else goes wrong) all workgroups drain, the launch
+// ends with ctl->abort set and the host falls back to the launch chain.
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+
+#include "stream_fit.h"
+
+namespace brdf {
+
+constexpr int kRThreads = 512;               // wave 0 = control wave, waves 1..7 = sample waves
+constexpr int kRWorkers = kRThreads - kWave;  // 448 lanes hold samples
+constexpr int kRSpt = 10;                     // samples per worker lane (448 * 10 = 4480 >= 4096)
+constexpr int kRTile = 4096;                  // samples per workgroup (so that #CUs * kRTile >= 2^20 on MI355X)
+constexpr int kRCap = kRWorkers * kRSpt;      // sample slots per workgroup
+constexpr int kRowWords = 2 * kSlots;         // 8-byte granules per partial row: 2 per slot
+constexpr int kRowStride = 256;               // workgroups per granule word (>= #CUs), a whole number of lines
+constexpr int kRedCols = kRWorkers / 4;       // reduction buffer columns (after two in-row DPP steps)
+constexpr long long kSpinBudgetTicks = 200000000LL;  // 2 s of s_memrealtime (100 MHz) per wait
+
+typedef unsigned long long u64;
+
+struct ResidentCtl {  // zeroed before every launch (uploaded together with the machine)
+  unsigned abort;
+  unsigned domain_bad;
+  unsigned pad[30];
+};
+
+struct ResidentCtx {
+  const double *c0, *c1, *c2, *x;
+  u64 *rows;            // [2][kRowWords][kRowStride] tagged granules; every tag stored so far is <= tag_base
+  ResidentCtl *ctl;
+  const void *machine0;  // DifMachine<3> / BcMachine<3> as started by the host
+  Mailbox *mbox;
+  int n;
+  unsigned tag_base;  // tags of this launch are tag_base + epoch + 1: the rows need no zeroing between launches
+};
+
+template <int METHOD>
+using RMachine = typename std::conditional<METHOD == 0, DifMachine<kM>, BcMachine<kM>>::type;
+
+__device__ __forceinline__ void put_value(u64 *rows, int word, int wg, unsigned tag, double v) {
+  const u64 bits = (u64)__double_as_longlong(v);
+  __hip_atomic_store(rows + (size_t)word * kRowStride + wg, ((u64)tag << 32) | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(rows + (size_t)(word + 1) * kRowStride + wg, ((u64)tag << 32) | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64 get_granule(const u64 *g) { return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double join_halves(u64 lo, u64 hi) { return __longlong_as_double((long long)((lo & 0xffffffffull) | (hi << 32))); }
+
+#ifdef BRDF_STAMPS
+#define RSTAMP(i) do { const long long now_ = clock64(); st_[i] += now_ - last_; last_ = now_; } while (0)
+#else
+#define RSTAMP(i) do {} while (0)
+#endif
+
+// Reduction of NS sums and one max over the seven sample waves (executed by those waves only; the control wave
+// joins the two barriers): two DPP steps inside each row of 16 lanes leave the sum of every 4 consecutive lanes in
+// lanes 3,7,11,..; those park their values as buf[slot][worker/4]; sample wave w (1..7) then owns slots {w-1, w+6}:
+// each lane adds its entries and one DPP tree per slot finishes it.  A pure function of NS: reproducible.
+template <int NS>
+__device__ __forceinline__ void worker_reduce(const double *acc, double mx, double *buf, double *out) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = (threadIdx.x >> 6) - 1;       // 0..6
+  const int wt = threadIdx.x - kWave;            // 0..447
+  double v[NS + 1];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    double t = acc[k];
+    t = t + dpp_move<0x111, 0xf, 0xf>(t, 0.0);  // row_shr:1
+    t = t + dpp_move<0x112, 0xf, 0xf>(t, 0.0);  // row_shr:2
+    v[k] = t;
+  }
+  {
+    double t = mx;
+    t = fmax(t, dpp_move<0x111, 0xf, 0xf>(t, 0.0));
+    t = fmax(t, dpp_move<0x112, 0xf, 0xf>(t, 0.0));
+    v[NS] = t;
+  }
+  if ((wt & 3) == 3) {
+#pragma unroll
+    for (int k = 0; k <= NS; ++k) buf[k * kRedCols + (wt >> 2)] = v[k];
+  }
+  __syncthreads();  // X1
+  for (int k = wave; k <= NS; k += kRWorkers / kWave) {  // wave-uniform loop
+    const double *src = buf + k * kRedCols;
+    const bool two = lane + kWave < kRedCols;
+    double s = src[lane];
+    if (k < NS) {
+      s += two ? src[lane + kWave] : 0.0;
+      s = wave_reduce_to_last<OpSum>(s);
+      if (lane == kWave - 1) out[k] = s;
+    } else {
+      s = fmax(s, two ? src[lane + kWave] : 0.0);
+      s = wave_reduce_to_last<OpMax>(s);
+      if (lane == kWave - 1) out[kSums] = s;
+    }
+  }
+  __syncthreads();  // X2
+}
+
+// The exchange, executed by the control wave.  Granule layout: rows[parity][word][workgroup], word = 2*slot + half.
+// Lanes 0..NS-1 and lane 13 publish this workgroup's sums / max (two granules each); lane l then gathers the rows of
+// workgroups l, l+64, l+128, l+192 one after the other, so every load instruction of the wave reads 64 consecutive
+// 8-byte words (4 lines).  A lane first probes ONE word of a row and only then loads the row, so that waiting lanes
+// do not flood the L2 channels with full-row re-reads while the slowest workgroup is still sweeping.  The fold order
+// (each lane its rows in ascending order, then one DPP tree over the lanes) is fixed.  false = wait abandoned.
+template <int NS>
+__device__ __forceinline__ bool control_exchange(const ResidentCtx &ctx, unsigned epoch, double *sums, int *s_abort,
+                                                 long long *st_, long long &last_) {
+  const int lane = threadIdx.x;  // control wave = wave 0
+  const int G = gridDim.x;
+  const unsigned tag = ctx.tag_base + epoch + 1u;
+  u64 *rows = ctx.rows + (size_t)(epoch & 1u) * kRowWords * kRowStride;
+  if (lane < NS)
+    put_value(rows, 2 * lane, blockIdx.x, tag, sums[lane]);
+  else if (lane == kSums)
+    put_value(rows, 2 * kSums, blockIdx.x, tag, sums[kSums]);
+
+  double pv[NS];
+  double pmx = 0.0;
+#pragma unroll
+  for (int k = 0; k < NS; ++k) pv[k] = 0.0;
+  bool failed = false;
+  const long long t0 = (long long)wall_clock64();
+  for (int r = lane; r < G && !failed; r += kWave) {
+    const u64 *g = rows + r;
+    for (unsigned spins = 0;; ++spins) {
+      if ((unsigned)(get_granule(g + (size_t)(2 * kSums + 1) * kRowStride) >> 32) == tag) {
+        u64 w[2 * NS + 2];
+#pragma unroll
+        for (int k = 0; k < 2 * NS; ++k) w[k] = get_granule(g + (size_t)k * kRowStride);
+        w[2 * NS] = get_granule(g + (size_t)(2 * kSums) * kRowStride);
+        w[2 * NS + 1] = get_granule(g + (size_t)(2 * kSums + 1) * kRowStride);
+        bool ready = true;
+#pragma unroll
+        for (int k = 0; k < 2 * NS + 2; ++k) ready = ready && ((unsigned)(w[k] >> 32) == tag);
+        if (ready) {
+#pragma unroll
+          for (int k = 0; k < NS; ++k) pv[k] += join_halves(w[2 * k], w[2 * k + 1]);
+          pmx = fmax(pmx, join_halves(w[2 * NS], w[2 * NS + 1]));
+          break;
+        }
+      }
+      if ((spins & 63u) == 63u) {
+        if (__hip_atomic_load(&ctx.ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
+            (long long)wall_clock64() - t0 > kSpinBudgetTicks) {
+          __hip_atomic_store(&ctx.ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          failed = true;
+          break;
+        }
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  RSTAMP(2);
+  if (__any(failed)) {
+    *s_abort = 1;
+    return false;
+  }
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    const double t = wave_reduce_to_last<OpSum>(pv[k]);
+    if (lane == kWave - 1) sums[k] = t;
+  }
+  {
+    const double t = wave_reduce_to_last<OpMax>(pmx);
+    if (lane == kWave - 1) sums[kSums] = t;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  RSTAMP(3);
+  return true;
+}
+
+template <int MODEL, int METHOD, bool FAST>
+__global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx) {
+  using Machine = RMachine<METHOD>;
+  using Mdl = BrdfModel<MODEL>;
+  static_assert(sizeof(Machine) % 4 == 0, "machine copied as dwords");
+  __shared__ Machine sm;
+  __shared__ PassUniforms<MODEL> su;
+  __shared__ double red[kSlots * kRedCols];
+  __shared__ double sums[kSlots];
+  __shared__ double dp_prev[kM + 1];  // Dp and ||Dp||^2 of the last trial (dif)
+  __shared__ int s_abort;
+  constexpr int kJl = (METHOD == 0) ? 3 * kRCap : 2;
+  __shared__ double jl[kJl];  // dif: the secant Jacobian, SoA planes
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int G = gridDim.x;
+  const int n = ctx.n;
+
+  {  // the started machine, written by the host before the launch
+    const unsigned *src = reinterpret_cast<const unsigned *>(ctx.machine0);
+    unsigned *dst = reinterpret_cast<unsigned *>(&sm);
+    for (int w = tid; w < (int)(sizeof(Machine) / 4); w += kRThreads) dst[w] = src[w];
+    if (tid == 0) s_abort = 0;
+    if (tid <= kM) dp_prev[tid] = 0.0;
+  }
+  __syncthreads();
+  if (wave == 0) su.build(sm.h.req);
+  __syncthreads();
+
+  if (wave == 0) {
+    // =========================== control wave: exchange, fold, LM step ===========================================
+    // All 64 lanes execute the scalar step with identical values (stream_fit.hip explains why that beats one lane).
+    long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long last_ = clock64();
+    long long n_jac = 0;
+    const long long t_first = (long long)wall_clock64();
+    unsigned epoch = 0;
+    for (;; ++epoch) {
+      const int kind = sm.h.req.kind;
+      if (kind == RQ_DONE) break;
+      if (kind == RQ_JAC || kind == RQ_DIF_JAC) ++n_jac;
+      __syncthreads();  // X1 (worker_reduce)
+      __syncthreads();  // X2: sums[] hold this workgroup's partial sums
+      RSTAMP(1);
+      bool alive;
+      switch (kind) {
+      case RQ_JAC: alive = control_exchange<SumLayout<kM>::JAC>(ctx, epoch, sums, &s_abort, st_, last_); break;
+      case RQ_DIF_JAC: alive = control_exchange<SumLayout<kM>::DIF_JAC>(ctx, epoch, sums, &s_abort, st_, last_); break;
+      case RQ_DIF_TRIAL: alive = control_exchange<SumLayout<kM>::DIF_TRIAL>(ctx, epoch, sums, &s_abort, st_, last_); break;
+      case RQ_EVAL_MULTI: alive = control_exchange<kMaxCand>(ctx, epoch, sums, &s_abort, st_, last_); break;
+      default: alive = control_exchange<1>(ctx, epoch, sums, &s_abort, st_, last_); break;
+      }
+      if (!alive) {  // give up: the host sees no `done`, reads ctl->abort and falls back
+        __syncthreads();  // B (the sample waves read s_abort behind it)
+        return;
+      }
+      if (kind == RQ_DIF_TRIAL) {
+#pragma unroll
+        for (int j = 0; j < kM; ++j) dp_prev[j] = su.dp[j];
+        dp_prev[kM] = su.dp_l2;
+      }
+      sm.template step<true>(sums, sums[kSums]);
+      if (sm.h.req.kind != RQ_DONE) su.build(sm.h.req);
+      __syncthreads();  // B: the next request and its uniforms are in LDS
+      RSTAMP(4);
+    }
+    if (blockIdx.x == 0 && tid == 0) {  // every workgroup holds the same finished machine; workgroup 0 reports
+      Mailbox *mb = ctx.mbox;
+      mb->ret = sm.c.ret;
+      mb->passes = (int)epoch;
+      if constexpr (METHOD == 1)
+        mb->infeasible_mask = sm.c.infeasible_mask;
+      else
+        mb->infeasible_mask = 0;
+      mb->domain_bad = (int)__hip_atomic_load(&ctx.ctl->domain_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      mb->n_jac = n_jac;
+      mb->n_eval = (long long)epoch - n_jac;
+      mb->t_first = t_first;
+      mb->t_last = (long long)wall_clock64();
+      for (int k = 0; k < 8; ++k) mb->stamps[k] = st_[k];
+      for (int i = 0; i < kM; ++i) mb->p[i] = sm.h.p[i];
+      for (int i = 0; i < kInfoSz; ++i) mb->info[i] = sm.c.info[i];
+      for (int i = 0; i < kM * kM; ++i) mb->covar[i] = sm.c.covar[i];
+      __threadfence_system();
+      __hip_atomic_store(&mb->done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    return;
+  }
+
+  // ============================= sample waves: the resident tile and the sweeps ================================
+  const int wt = tid - kWave;  // 0..447
+  int vb = blockIdx.x;         // same XCD-contiguous dealing of tiles as the launch chain
+  if ((G & 7) == 0) vb = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+  const int tile = (n + G - 1) / G;  // <= kRTile, checked on the host
+  const int begin = vb * tile;
+  const int end = min(n, begin + tile);
+  const int nk = (tile + kRWorkers - 1) / kRWorkers;  // occupied sample slots of a lane (workgroup-uniform)
+  double s0[kRSpt], sx[kRSpt];
+  Prep pq[kRSpt];
+  unsigned okm = 0;
+  {
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < kRSpt; ++k) {
+      const int i = begin + wt + k * kRWorkers;
+      const bool ok = i < end;
+      okm |= ok ? (1u << k) : 0u;
+      const int ii = ok ? i : begin;
+      s0[k] = ctx.c0[ii];
+      const double r1 = Mdl::uses_c1 ? ctx.c1[ii] : 0.0;
+      const double r2 = Mdl::uses_c2 ? ctx.c2[ii] : 0.0;
+      sx[k] = ctx.x[ii];
+      pq[k] = Mdl::template prepare<FAST>(s0[k], r1, r2);
+      if (FAST && ok && !Mdl::domain_ok(s0[k], r1, r2)) bad = true;
+    }
+    if (FAST && bad) __hip_atomic_store(&ctx.ctl->domain_bad, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  double hx[METHOD == 0 ? kRSpt : 1], wrk[METHOD == 0 ? kRSpt : 1];
+  if constexpr (METHOD == 0) {
+#pragma unroll
+    for (int k = 0; k < kRSpt; ++k) hx[k] = wrk[k] = 0.0;
+  }
+  int cur_sel_hx = 0, cur_sel_j = 0;
+
+  for (;;) {
+    const int kind = sm.h.req.kind;
+    if (kind == RQ_DONE) break;
+    const PassUniforms<MODEL> &u = su;
+
+    if constexpr (METHOD == 0) {  // commit what the machine decided about the previous trial (speculative protocol)
+      if (sm.h.req.sel_j != cur_sel_j) {  // adopt the Broyden update J += ((wrk - hx - J Dp)/||Dp||^2) Dp^T, lm_core.c:760-766
+#pragma unroll
+        for (int k = 0; k < kRSpt; ++k) if (k < nk) {
+          const int s = k * kRWorkers + wt;
+          const double jo[kM] = {jl[s], jl[kRCap + s], jl[2 * kRCap + s]};
+          double t = 0.0;
+#pragma unroll
+          for (int l = 0; l < kM; ++l) t += jo[l] * dp_prev[l];
+          t = (wrk[k] - hx[k] - t) / dp_prev[kM];
+#pragma unroll
+          for (int j = 0; j < kM; ++j) jl[j * kRCap + s] = jo[j] + t * dp_prev[j];
+        }
+        cur_sel_j = sm.h.req.sel_j;
+      }
+      if (sm.h.req.sel_hx != cur_sel_hx) {  // step accepted: hx <- f(p + Dp)
+#pragma unroll
+        for (int k = 0; k < kRSpt; ++k) hx[k] = wrk[k];
+        cur_sel_hx = sm.h.req.sel_hx;
+      }
+    }
+
+    double acc[kSums];
+#pragma unroll
+    for (int k = 0; k < kSums; ++k) acc[k] = 0.0;
+    double mx = 0.0;
+    switch (kind) {
+    case RQ_EVAL:
+#pragma unroll
+      for (int k = 0; k < kRSpt; ++k) if (k < nk) {
+        const double f = model_value<MODEL, FAST>(u, s0[k], pq[k]);
+        const double e = (okm >> k & 1u) ? sx[k] - f : 0.0;
+        acc[0] += e * e;
+        mx = fmax(mx, fabs(e));
+      }
+      worker_reduce<1>(acc, mx, red, sums);
+      break;
+    case RQ_SCALED:
+#pragma unroll
+      for (int k = 0; k < kRSpt; ++k) if (k < nk) {
+        const double f = model_value<MODEL, FAST>(u, s0[k], pq[k]);
+        const double t = (okm >> k & 1u) ? (sx[k] - f) / u.scal : 0.0;
+        acc[0] += t * t;
+      }
+      worker_reduce<1>(acc, mx, red, sums);
+      break;
+    case RQ_EVAL_MULTI:
+#pragma unroll
+      for (int k = 0; k < kRSpt; ++k) if (k < nk) {
+#pragma unroll
+        for (int j = 0; j < kMaxCand; ++j)
+          if (j < u.ncand) {
+            const double e = (okm >> k & 1u) ? sx[k] - model_value_k<MODEL, FAST>(u, j, s0[k], pq[k]) : 0.0;
+            acc[j] += e * e;
+          }
+      }
+      worker_reduce<kMaxCand>(acc, mx, red, sums);
+      break;
+    case RQ_JAC:
+#pragma unroll
+      for (int k = 0; k < kRSpt; ++k) if (k < nk) {
+        double f0 = 0.0, j[kM];
+        model_fd_row<MODEL, FAST>(u, s0[k], pq[k], true, f0, 0.0, false, j);
+        double e = sx[k] - f0;
+        if (!(okm >> k & 1u)) e = j[0] = j[1] = j[2] = 0.0;
+        acc_normal_eq(j, e, acc, acc + kNL);
+        acc[kNL + kM] += e * e;
+      }
+      worker_reduce<SumLayout<kM>::JAC>(acc, mx, red, sums);
+      break;
+    case RQ_DIF_INIT:
+      if constexpr (METHOD == 0) {
+#pragma unroll
+        for (int k = 0; k < kRSpt; ++k) if (k < nk) {
+          hx[k] = model_value<MODEL, FAST>(u, s0[k], pq[k]);
+          const double e = (okm >> k & 1u) ? sx[k] - hx[k] : 0.0;
+          acc[0] += e * e;
+        }
+      }
+      worker_reduce<1>(acc, mx, red, sums);
+      break;
+    case RQ_DIF_JAC:
+      if constexpr (METHOD == 0) {
+#pragma unroll
+        for (int k = 0; k < kRSpt; ++k) if (k < nk) {
+          const int s = k * kRWorkers + wt;
+          double f0 = 0.0, j[kM];
+          model_fd_row<MODEL, FAST>(u, s0[k], pq[k], false, f0, hx[k], true, j);
+          double e = sx[k] - hx[k];
+          if (!(okm >> k & 1u)) e = j[0] = j[1] = j[2] = 0.0;
+          jl[s] = j[0];
+          jl[kRCap + s] = j[1];
+          jl[2 * kRCap + s] = j[2];
+          acc_normal_eq(j, e, acc, acc + kNL);
+        }
+      }
+      worker_reduce<SumLayout<kM>::DIF_JAC>(acc, mx, red, sums);
+      break;
+    case RQ_DIF_TRIAL:  // speculative protocol: the Broyden-updated row is formed for the sums only; J itself is
+                        // updated (from wrk, hx) at the top of the next pass if the machine adopts it
+      if constexpr (METHOD == 0) {
+#pragma unroll
+        for (int k = 0; k < kRSpt; ++k) if (k < nk) {
+          const int s = k * kRWorkers + wt;
+          const double w = model_value_q<MODEL, FAST>(u, s0[k], pq[k]);
+          const double jo[kM] = {jl[s], jl[kRCap + s], jl[2 * kRCap + s]};
+          double jn[kM];
+          broyden_row(jo, w, hx[k], u.dp, u.dp_l2, jn);
+          double en = sx[k] - w, eo = sx[k] - hx[k];
+          if (!(okm >> k & 1u)) en = eo = jn[0] = jn[1] = jn[2] = 0.0;
+          wrk[k] = w;
+          acc[0] += en * en;
+          acc_normal_eq(jn, en, acc + 1, acc + 1 + kNL);
+          acc[1 + kNL + kM + 0] += jn[0] * eo;
+          acc[1 + kNL + kM + 1] += jn[1] * eo;
+          acc[1 + kNL + kM + 2] += jn[2] * eo;
+        }
+      }
+      worker_reduce<SumLayout<kM>::DIF_TRIAL>(acc, mx, red, sums);
+      break;
+    default:  // unknown request: keep the barrier protocol, the control wave will not survive it either
+      worker_reduce<1>(acc, mx, red, sums);
+      break;
+    }
+    __syncthreads();  // B: the control wave has stepped the machine
+    if (s_abort) return;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+#define HIP_OK(call)                                                                  \
+  do {                                                                                \
+    hipError_t e_ = (call);                                                           \
+    if (e_ != hipSuccess) {                                                           \
+      set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return kLmError;                                                                \
+    }                                                                                 \
+  } while (0)
+
+namespace {
+
+struct RWorkspace {
+  int device = -1, cus = 0;
+  char *d_block = nullptr;  // ctl | machine | rows[2][kRowWords][kRowStride]
+  char *h_block = nullptr;  // pinned staging of ctl (zeros) | started machine: ONE upload per fit
+  Mailbox *h_mbox = nullptr, *d_mbox = nullptr;
+  static constexpr size_t kMachineBytes = 4096;
+  static constexpr size_t off_machine = sizeof(ResidentCtl);
+  static constexpr size_t off_rows = off_machine + kMachineBytes;
+  static constexpr size_t rows_bytes = sizeof(u64) * 2 * (size_t)kRowWords * kRowStride;
+  unsigned tag_base = 0;
+  FitStats stats{};
+
+  int ensure(int dev) {
+    if (device == dev && d_block) return 0;
+    device = dev;
+    hipDeviceProp_t prop;
+    HIP_OK(hipGetDeviceProperties(&prop, dev));
+    cus = prop.multiProcessorCount;
+    HIP_OK(hipMalloc(&d_block, off_rows + rows_bytes));
+    HIP_OK(hipMemset(d_block, 0, off_rows + rows_bytes));
+    tag_base = 0;
+    HIP_OK(hipHostMalloc(&h_block, off_rows, hipHostMallocDefault));
+    HIP_OK(hipHostMalloc(&h_mbox, sizeof(Mailbox), hipHostMallocMapped | hipHostMallocCoherent));
+    HIP_OK(hipHostGetDevicePointer((void **)&d_mbox, h_mbox, 0));
+    return 0;
+  }
+};
+thread_local RWorkspace g_rws;
+
+template <int MODEL, int METHOD, bool FAST>
+int resident_attempt(const StreamFitArgs &a, RWorkspace &ws, bool *retry_exact, bool *unavailable) {
+  using Machine = RMachine<METHOD>;
+  static_assert(sizeof(Machine) <= 4096, "resident workspace layout");
+  *retry_exact = *unavailable = false;
+  const int G = (int)std::min<long long>(ws.cus, std::max<long long>(1, ((long long)a.n + 1023) / 1024));
+  HIP_OK(hipStreamSynchronize(a.stream));  // (no-op on an idle stream) the pinned staging block is about to be rewritten
+  memset(ws.h_block, 0, RWorkspace::off_rows);
+  Machine &m = *reinterpret_cast<Machine *>(ws.h_block + RWorkspace::off_machine);
+  if constexpr (METHOD == 0) {
+    m.start(a.p, a.n, a.itmax, a.opts, a.covar != nullptr, /*speculative=*/1);
+    if (m.h.req.kind == RQ_DONE) {
+      set_error("dlevmar_dif(): cannot solve a problem with fewer measurements [%d] than unknowns [%d]", a.n, kM);
+      return kLmError;
+    }
+  } else {
+    m.start(a.p, a.n, a.lb, a.ub, a.dscl, a.itmax, a.opts, a.covar != nullptr, pg_candidates());
+    if (m.h.req.kind == RQ_DONE) {
+      switch (m.c.bad_input) {
+      case 1: set_error("dlevmar_bc_dif(): cannot solve a problem with fewer measurements [%d] than unknowns [%d]", a.n, kM); break;
+      case 2: set_error("dlevmar_bc_dif(): at least one lower bound exceeds the upper one"); break;
+      default: set_error("dlevmar_bc_dif(): scaling constants should be positive"); break;
+      }
+      return kLmError;
+    }
+    if (FAST || !brdf_fast_path_enabled())  // (an exact re-run must not print the warning twice)
+      for (int i = 0; i < kM; ++i)          // same warning as lmbc_core.c:516-520
+        if (m.c.infeasible_mask & (1 << i))
+          fprintf(stderr, "Warning: component %d of starting point not feasible in dlevmar_bc_dif()! [%g projected to %g]\n",
+                  i, m.c.p_start[i], m.h.p[i]);
+  }
+  Mailbox &mb = *ws.h_mbox;
+  memset(&mb, 0, sizeof mb);
+  if (ws.tag_base > 0xF0000000u) {  // tag space nearly used up: start over from zeroed rows
+    HIP_OK(hipMemsetAsync(ws.d_block + RWorkspace::off_rows, 0, RWorkspace::rows_bytes, a.stream));
+    ws.tag_base = 0;
+  }
+  HIP_OK(hipMemcpyAsync(ws.d_block, ws.h_block, RWorkspace::off_machine + sizeof(Machine), hipMemcpyHostToDevice, a.stream));
+
+  ResidentCtx c;
+  c.c0 = a.d_angles;
+  c.c1 = a.d_angles + a.n;
+  c.c2 = a.d_angles + 2 * (size_t)a.n;
+  c.x = a.d_x;
+  c.ctl = reinterpret_cast<ResidentCtl *>(ws.d_block);
+  c.rows = reinterpret_cast<u64 *>(ws.d_block + RWorkspace::off_rows);
+  c.machine0 = ws.d_block + RWorkspace::off_machine;
+  c.mbox = ws.d_mbox;
+  c.n = a.n;
+  c.tag_base = ws.tag_base;
+
+  hipLaunchKernelGGL((resident_fit_kernel<MODEL, METHOD, FAST>), dim3(G), dim3(kRThreads), 0, a.stream, c);
+  HIP_OK(hipGetLastError());
+  {  // wait on the pinned mailbox (a stream synchronise sleeps and wakes up tens of microseconds late); the launch
+     // always terminates (bounded spins), which hipStreamQuery reports even if `done` never comes
+    volatile int *done = &mb.done;
+    for (unsigned spins = 0; !*done; ++spins)
+      if ((spins & 0x3FFu) == 0x3FFu && hipStreamQuery(a.stream) != hipErrorNotReady) break;
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  }
+  if (!mb.done) {
+    HIP_OK(hipStreamSynchronize(a.stream));
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  }
+  if (!mb.done) {  // aborted: not co-resident / spin budget exhausted.  Tags of unknown epochs were stored: start over
+    (void)hipMemsetAsync(ws.d_block + RWorkspace::off_rows, 0, RWorkspace::rows_bytes, a.stream);
+    ws.tag_base = 0;
+    *unavailable = true;
+    return 0;
+  }
+  ws.tag_base += (unsigned)mb.passes + 2u;
+  if (FAST && mb.domain_bad) {
+    *retry_exact = true;
+    return 0;
+  }
+  for (int i = 0; i < kM; ++i) a.p[i] = mb.p[i];
+  if (a.info)
+    for (int i = 0; i < kInfoSz; ++i) a.info[i] = mb.info[i];
+  if (a.covar)
+    for (int i = 0; i < kM * kM; ++i) a.covar[i] = mb.covar[i];
+  ws.stats.passes = mb.passes;
+  ws.stats.launches = 1;
+  ws.stats.jac_passes = mb.n_jac;
+  ws.stats.eval_passes = mb.n_eval;
+  ws.stats.device_us = (double)(mb.t_last - mb.t_first) / 100.0;  // first pass start -> result (s_memrealtime, 100 MHz)
+  for (int k = 0; k < 8; ++k) ws.stats.stamps[k] = mb.stamps[k];
+  return mb.ret;
+}
+
+template <int MODEL, int METHOD>
+int resident_run_mm(const StreamFitArgs &a, RWorkspace &ws, bool *unavailable) {
+  bool retry = false;
+  double keep[kM];
+  for (int i = 0; i < kM; ++i) keep[i] = a.p[i];
+  int ret;
+  if (brdf_fast_path_enabled() || MODEL == MODEL_WARD) {
+    ret = resident_attempt<MODEL, METHOD, true>(a, ws, &retry, unavailable);
+    if (!retry || *unavailable) return ret;
+    for (int i = 0; i < kM; ++i) a.p[i] = keep[i];
+  }
+  if constexpr (MODEL != MODEL_WARD)
+    return resident_attempt<MODEL, METHOD, false>(a, ws, &retry, unavailable);
+  else
+    return kLmError;
+}
+
+}  // namespace
+
+FitStats resident_fit_last_stats() { return g_rws.stats; }
+
+// returns true if the resident path handled the fit (*ret is then the solver's return value)
+bool resident_fit_try(const StreamFitArgs &a, int *ret) {
+  // Default: dlevmar_dif only.  Measured on MI355X, 1M-sample Ward fit (bench.py, 20 fits): 16.6 us per dlevmar_dif
+  // pass against 19.7 us for the launch chain (the secant Jacobian no longer travels through HBM), but 12.2 us per
+  // dlevmar_bc_dif pass against 11.3 us: the in-launch all-gather of 256 rows costs ~6 us where the kernel boundary
+  // + partial-row reload cost ~4 us, and bc_dif has no per-sample state to save.
+  // BRDF_HIP_RESIDENT=0: always the launch chain; =1: resident for both entry points.
+  const char *e = getenv("BRDF_HIP_RESIDENT");
+  if (e && e[0] == '0') return false;
+  if (a.method != 0 && !(e && e[0] == '1')) return false;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  RWorkspace &ws = g_rws;
+  if (ws.ensure(dev) != 0) return false;
+  if ((long long)a.n > (long long)ws.cus * kRTile || ws.cus > kRowStride) return false;  // does not fit the chip: launch chain
+  bool unavailable = false;
+  int r;
+  switch (a.model * 2 + a.method) {
+  case 0: r = resident_run_mm<0, 0>(a, ws, &unavailable); break;
+  case 1: r = resident_run_mm<0, 1>(a, ws, &unavailable); break;
+  case 2: r = resident_run_mm<1, 0>(a, ws, &unavailable); break;
+  case 3: r = resident_run_mm<1, 1>(a, ws, &unavailable); break;
+  case 4: r = resident_run_mm<2, 0>(a, ws, &unavailable); break;
+  default: r = resident_run_mm<2, 1>(a, ws, &unavailable); break;
+  }
+  if (unavailable) {
+    static bool warned = false;
+    if (!warned) fprintf(stderr, "libbrdf_hip: resident single-launch path unavailable (grid not co-resident?); using the launch chain\n");
+    warned = true;
+    return false;
+  }
+  *ret = r;
+  return true;
+}
+
+}  // namespace brdf

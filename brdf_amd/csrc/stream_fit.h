@@ -78,9 +78,9 @@ struct FitStats {
 };
 FitStats stream_fit_last_stats();
 
-// persistent single-launch variant (persist_fit.hip): true if it handled the fit
-bool persist_fit_try(const StreamFitArgs &a, int *ret);
-FitStats persist_fit_last_stats();
+// resident single-launch regime (resident_fit.hip): true if it handled the fit
+bool resident_fit_try(const StreamFitArgs &a, int *ret);
+FitStats resident_fit_last_stats();
 
 bool brdf_fast_path_enabled();  // false when BRDF_HIP_EXACT_POW=1
 int pg_candidates();            // BRDF_HIP_PG_MULTI (default kMaxCand)

@@ -18,6 +18,14 @@
 #include <cstring>
 #include <type_traits>
 
+#if defined(BRDF_STAMPS)
+#include <hip/hip_runtime.h>
+__device__ long long g_lm_stamps[8];  // diagnostic: cycles per section of DifMachine::run, block 0 only
+__device__ long long g_lm_last;
+#endif
+#if defined(BRDF_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+#define LM_STAMP(i) do { if (blockIdx.x == 0) { const long long now_ = clock64(); if ((i) != 0) g_lm_stamps[i] += now_ - g_lm_last; g_lm_last = now_; } } while (0)
+#endif
 #include "stream_fit.h"
 
 namespace brdf {
@@ -470,8 +478,8 @@ int blocks_for(int n) {
 
 }  // namespace
 
-static thread_local bool g_last_was_persistent = false;
-FitStats stream_fit_last_stats() { return g_last_was_persistent ? persist_fit_last_stats() : g_ws.stats; }
+static thread_local bool g_last_was_resident = false;
+FitStats stream_fit_last_stats() { return g_last_was_resident ? resident_fit_last_stats() : g_ws.stats; }
 bool brdf_fast_path_enabled();
 int pg_candidates();
 
@@ -581,6 +589,11 @@ static int stream_fit_attempt(const StreamFitArgs &a, bool fast, bool *retry_exa
     static StreamCtx tmp;
     (void)hipStreamSynchronize(a.stream);
     (void)hipMemcpy(&tmp, ws.d_ctx, sizeof tmp, hipMemcpyDeviceToHost);
+    long long ls[8];
+    if (hipMemcpyFromSymbol(ls, HIP_SYMBOL(g_lm_stamps), sizeof ls) == hipSuccess) {
+      fprintf(stderr, "lm step sections (cycles, summed over %d passes, cumulative since load): after_trial=%lld top+gradient=%lld lu_solve=%lld rest_of_solve=%lld\n",
+              mb.passes, ls[1], ls[2], ls[3], ls[4]);
+    }
     if (FILE *f = fopen(path, "a")) {
       for (int i = 1; i < mb.passes && i < 4096; ++i) fprintf(f, "%d %d %d %d\n", a.method, tmp.dbg[i * 4], tmp.dbg[i * 4 + 1], tmp.dbg[i * 4 + 2]);
       fclose(f);
@@ -631,14 +644,14 @@ int stream_fit_run(const StreamFitArgs &a) {
 
   double p_keep[kM];
   for (int i = 0; i < kM; ++i) p_keep[i] = a.p[i];
-  {  // fits that fit the chip's register file run as ONE persistent launch (persist_fit.hip)
+  {  // fits that fit the chip's registers + LDS run as ONE launch with the samples resident (resident_fit.hip)
     int pret = 0;
-    if (persist_fit_try(a, &pret)) {
-      g_last_was_persistent = true;
+    if (resident_fit_try(a, &pret)) {
+      g_last_was_resident = true;
       return pret;
     }
     for (int i = 0; i < kM; ++i) a.p[i] = p_keep[i];
-    g_last_was_persistent = false;
+    g_last_was_resident = false;
   }
   bool retry = false;
   int ret = stream_fit_attempt(a, brdf_fast_path_enabled(), &retry);

@@ -4,7 +4,8 @@ import numpy as np, torch
 import brdf_amd
 from brdf_amd import synth
 dev = torch.device("cuda:0")
-names = ["load", "fold", "step", "uniforms", "persist", "sweep", "reduce"]
+names = ["load", "fold", "step", "uniforms", "persist", "sweep", "reduce"]           # launch chain (stream_fit.hip)
+names_res = ["-", "sweep+reduce", "gather", "fold", "step+build", "-", "-"]   # resident regime, control wave view (resident_fit.hip)
 for model, n in [(2, 4096), (2, 1_000_000), (1, 1_000_000)]:
     angles, x, _ = synth.make_single(model, n)
     a = torch.from_numpy(angles).to(dev); xd = torch.from_numpy(x).to(dev)
@@ -14,4 +15,4 @@ for model, n in [(2, 4096), (2, 1_000_000), (1, 1_000_000)]:
         out = (C.c_longlong * 8)(); brdf_amd.lib.brdf_hip_last_fit_stamps(out)
         P = max(1, st['passes'] - 1)
         print(model, n, method, r.ret, 'us/pass %.2f' % (st['device_us'] / st['passes']),
-              ' '.join(f"{nm}={out[k]/P:.0f}" for k, nm in enumerate(names)), 'cycles/pass', flush=True)
+              'launches', st['launches'], ' '.join(f"{nm}={out[k]/P:.0f}" for k, nm in enumerate(names_res if st['launches'] == 1 else names)), 'cycles/pass', flush=True)

@@ -15,6 +15,6 @@ agg = collections.defaultdict(list)
 for line in open(path):
     m, cyc, kinds, phases = map(int, line.split())
     agg[(m, kinds, phases)].append(cyc)
-names = {0:'DONE',1:'EVAL',2:'SCALED',3:'JAC',4:'DIF_INIT',5:'DIF_JAC',6:'DIF_TRIAL',7:'DIF_UPDATE'}
+names = {0:'DONE',1:'EVAL',2:'SCALED',3:'JAC',4:'DIF_INIT',5:'DIF_JAC',6:'DIF_TRIAL',7:'DIF_UPDATE',8:'EVAL_MULTI'}
 for (m, kinds, phases), v in sorted(agg.items(), key=lambda kv: -len(kv[1])):
     print(f"method={m} {names[kinds//100]:>9s}->{names[kinds%100]:<9s} phase {phases//100:2d}->{phases%100:2d}  n={len(v):5d}  mean={np.mean(v):7.0f}  min={min(v):6d} max={max(v):6d} cycles")

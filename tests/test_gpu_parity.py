@@ -300,16 +300,25 @@ def test_device_generator_matches_host_generator(gpu):
     assert np.max(np.abs(xd.cpu().numpy() - x)) <= 1e-15  # measurements: device exp vs numpy exp
 
 
-def test_persistent_single_launch_variant(gpu, monkeypatch):
-    """opt-in alternative of the streamed regime (persist_fit.hip): the whole fit in ONE launch, samples and the
-    secant Jacobian in registers, passes separated by a ticket/flag hand-off.  Same machines, same parity bar."""
-    monkeypatch.setenv("BRDF_HIP_PERSISTENT", "1")
-    for model, n in ((2, 100000), (1, 5000), (0, 300)):
-        angles, x, _ = synth.make_single(model, n)
-        for method in (0, 1):
-            _, p_ref, info_ref = L.brdf_fit("orc", method, model, angles, x, synth.P0[model], synth.ITMAX, synth.OPTS,
-                                            synth.LB, synth.UB)
-            _check(_dev_fit(gpu, method, model, angles, x), p_ref, info_ref)
+def test_resident_and_launch_chain_regimes(gpu, monkeypatch):
+    """A single fit that fits the chip (n <= #CUs * 4096) can run in ONE launch with its samples resident in
+    registers/LDS (resident_fit.hip, passes separated by an in-launch all-gather of tagged granules) or as the launch
+    chain (stream_fit.hip, one launch per pass).  Default: resident for dlevmar_dif, chain for dlevmar_bc_dif;
+    BRDF_HIP_RESIDENT=1 / =0 force one regime for both.  Same machines, same parity bar, everything covered."""
+    torch, brdf_amd, dev = gpu
+    for env in ("1", "0", ""):
+        if env:
+            monkeypatch.setenv("BRDF_HIP_RESIDENT", env)
+        else:
+            monkeypatch.delenv("BRDF_HIP_RESIDENT")
+        for model, n in ((2, 100000), (1, 5000), (0, 300)):
+            angles, x, _ = synth.make_single(model, n)
+            for method in (0, 1):
+                _, p_ref, info_ref = L.brdf_fit("orc", method, model, angles, x, synth.P0[model], synth.ITMAX, synth.OPTS,
+                                                synth.LB, synth.UB)
+                _check(_dev_fit(gpu, method, model, angles, x), p_ref, info_ref)
+                st = brdf_amd.last_fit_stats()
+                assert (st["launches"] == 1) == (env == "1" or (env == "" and method == 0)), st
 
 
 def test_diagonal_scaling_and_nan_input(gpu):
