@@ -179,7 +179,7 @@ def main():
     def run(method, steps, warmup):
         for _ in range(warmup):
             brdf_amd.fit_single(method, MODEL, a_dev, x_dev, p0, lb=lb, ub=ub, itmax=itmax, opts=opts)
-        results = torch.zeros((steps, 13), dtype=torch.float64)
+        res_np = np.zeros((steps, 13))  # filled inside the timed loop (numpy: ~1 us per row; torch CPU indexing costs ~20 us)
         passes = jac = launches = 0
         dev_us = 0.0
         if world > 1:
@@ -192,14 +192,15 @@ def main():
             r = brdf_amd.fit_single(method, MODEL, a_dev, x_dev, p0, lb=lb, ub=ub, itmax=itmax, opts=opts)
             if r.ret < 0:
                 raise RuntimeError(f"fit failed: {brdf_amd.last_error()}")
-            results[s, :3] = torch.from_numpy(r.p)
-            results[s, 3:] = torch.from_numpy(r.info)
+            res_np[s, :3] = r.p
+            res_np[s, 3:] = r.info
             st = brdf_amd.last_fit_stats()
             passes += st["passes"]
             launches += st["launches"]
             jac += st["jac_passes"]
             dev_us += st["device_us"]
         ev1.record()
+        results = torch.from_numpy(res_np)
         gathered = None
         if world > 1:  # the one collective of the job: fitted parameters + info[] of every step -> rank 0
             res_dev = results.to(coll_dev)

@@ -59,6 +59,7 @@ struct ResidentCtl {  // zeroed before every launch (uploaded together with the 
 struct ResidentCtx {
   const double *c0, *c1, *c2, *x;
   u64 *rows;            // [2][kRowWords][kRowStride] tagged granules; every tag stored so far is <= tag_base
+  u64 *groups;          // [2][kRowWords][kGroupStride]: sums over groups of 16 workgroups, same granule format
   ResidentCtl *ctl;
   const void *machine0;  // DifMachine<3> / BcMachine<3> as started by the host
   Mailbox *mbox;
@@ -69,10 +70,10 @@ struct ResidentCtx {
 template <int METHOD>
 using RMachine = typename std::conditional<METHOD == 0, DifMachine<kM>, BcMachine<kM>>::type;
 
-__device__ __forceinline__ void put_value(u64 *rows, int word, int wg, unsigned tag, double v) {
+__device__ __forceinline__ void put_value(u64 *rows, int stride, int word, int col, unsigned tag, double v) {
   const u64 bits = (u64)__double_as_longlong(v);
-  __hip_atomic_store(rows + (size_t)word * kRowStride + wg, ((u64)tag << 32) | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(rows + (size_t)(word + 1) * kRowStride + wg, ((u64)tag << 32) | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(rows + (size_t)word * stride + col, ((u64)tag << 32) | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(rows + (size_t)(word + 1) * stride + col, ((u64)tag << 32) | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ u64 get_granule(const u64 *g) { return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double join_halves(u64 lo, u64 hi) { return __longlong_as_double((long long)((lo & 0xffffffffull) | (hi << 32))); }
@@ -128,46 +129,47 @@ __device__ __forceinline__ void worker_reduce(const double *acc, double mx, doub
   __syncthreads();  // X2
 }
 
-// The exchange, executed by the control wave.  Granule layout: rows[parity][word][workgroup], word = 2*slot + half.
-// Lanes 0..NS-1 and lane 13 publish this workgroup's sums / max (two granules each); lane l then gathers the rows of
-// workgroups l, l+64, l+128, l+192 one after the other, so every load instruction of the wave reads 64 consecutive
-// 8-byte words (4 lines).  A lane first probes ONE word of a row and only then loads the row, so that waiting lanes
-// do not flood the L2 channels with full-row re-reads while the slowest workgroup is still sweeping.  The fold order
-// (each lane its rows in ascending order, then one DPP tree over the lanes) is fixed.  false = wait abandoned.
-template <int NS>
-__device__ __forceinline__ bool control_exchange(const ResidentCtx &ctx, unsigned epoch, double *sums, int *s_abort,
-                                                 long long *st_, long long &last_) {
-  const int lane = threadIdx.x;  // control wave = wave 0
-  const int G = gridDim.x;
-  const unsigned tag = ctx.tag_base + epoch + 1u;
-  u64 *rows = ctx.rows + (size_t)(epoch & 1u) * kRowWords * kRowStride;
-  if (lane < NS)
-    put_value(rows, 2 * lane, blockIdx.x, tag, sums[lane]);
-  else if (lane == kSums)
-    put_value(rows, 2 * kSums, blockIdx.x, tag, sums[kSums]);
+// The exchange, executed by the control wave: a two-level gather.  (A flat all-gather -- every workgroup reading all
+// 256 rows -- was measured at 6.2 us: 256 readers per line make the few hundred lines of the row table a hot spot
+// of the memory side; more loads in flight per reader made it slower, not faster.)
+//
+//   level 1  rows [parity][word][workgroup], word = 2*slot + half: every workgroup publishes its NS sums + max
+//            (lanes 0..NS-1 and lane 13, two granules each).  Workgroups are grouped 16 by 16; the first one of a group
+//            is its leader: lanes 0..15 of its control wave each gather one member's row (a wave load instruction
+//            reads 16 consecutive words = ONE line), fold the 16 rows with a DPP row reduction (fixed order) and
+//            lane 15 publishes the group's sums into
+//   level 2  groups [parity][word][group]: 16 groups x 8 B = one line per word.  Every workgroup (leaders too)
+//            gathers the <=16 group rows the same way and folds them: identical bits everywhere.
+//
+// On level 2 (256 readers per line) a lane first probes ONE word of its row (the last one its producer stores) and
+// only then loads the row, and waits between probes: the lines being polled are the ones the producers have to
+// write.  On level 1 (one reader per line) the row is simply re-read until all its tags match.  false = wait abandoned.
+constexpr int kGroup = 16;
+constexpr int kGroupStride = 16;  // group rows per granule word (>= ceil(#CUs / kGroup)), one 128-B line
 
-  double pv[NS];
-  double pmx = 0.0;
+template <int NS>
+__device__ __forceinline__ bool gather_row(const ResidentCtx &ctx, const u64 *g, int stride, unsigned tag, bool probe, bool active,
+                                           double (&pv)[NS], double &pmx) {
 #pragma unroll
   for (int k = 0; k < NS; ++k) pv[k] = 0.0;
+  pmx = 0.0;
   bool failed = false;
-  const long long t0 = (long long)wall_clock64();
-  for (int r = lane; r < G && !failed; r += kWave) {
-    const u64 *g = rows + r;
+  if (active) {
+    const long long t0 = (long long)wall_clock64();
     for (unsigned spins = 0;; ++spins) {
-      if ((unsigned)(get_granule(g + (size_t)(2 * kSums + 1) * kRowStride) >> 32) == tag) {
+      if (!probe || (unsigned)(get_granule(g + (size_t)(2 * kSums + 1) * stride) >> 32) == tag) {
         u64 w[2 * NS + 2];
 #pragma unroll
-        for (int k = 0; k < 2 * NS; ++k) w[k] = get_granule(g + (size_t)k * kRowStride);
-        w[2 * NS] = get_granule(g + (size_t)(2 * kSums) * kRowStride);
-        w[2 * NS + 1] = get_granule(g + (size_t)(2 * kSums + 1) * kRowStride);
+        for (int k = 0; k < 2 * NS; ++k) w[k] = get_granule(g + (size_t)k * stride);
+        w[2 * NS] = get_granule(g + (size_t)(2 * kSums) * stride);
+        w[2 * NS + 1] = get_granule(g + (size_t)(2 * kSums + 1) * stride);
         bool ready = true;
 #pragma unroll
         for (int k = 0; k < 2 * NS + 2; ++k) ready = ready && ((unsigned)(w[k] >> 32) == tag);
         if (ready) {
 #pragma unroll
-          for (int k = 0; k < NS; ++k) pv[k] += join_halves(w[2 * k], w[2 * k + 1]);
-          pmx = fmax(pmx, join_halves(w[2 * NS], w[2 * NS + 1]));
+          for (int k = 0; k < NS; ++k) pv[k] = join_halves(w[2 * k], w[2 * k + 1]);
+          pmx = join_halves(w[2 * NS], w[2 * NS + 1]);
           break;
         }
       }
@@ -179,22 +181,57 @@ __device__ __forceinline__ bool control_exchange(const ResidentCtx &ctx, unsigne
           break;
         }
       }
-      __builtin_amdgcn_s_sleep(1);
+      if (probe)
+        __builtin_amdgcn_s_sleep(2);  // many readers of one line: leave the line to its producers between probes
+      else
+        __builtin_amdgcn_s_sleep(1);
     }
   }
+  return !__any(failed);
+}
+
+template <int NS>
+__device__ __forceinline__ bool control_exchange(const ResidentCtx &ctx, unsigned epoch, double *sums, int *s_abort,
+                                                 long long *st_, long long &last_) {
+  const int lane = threadIdx.x;  // control wave = wave 0
+  const int G = gridDim.x;
+  const int grp = blockIdx.x / kGroup, ngrp = (G + kGroup - 1) / kGroup;
+  const unsigned tag = ctx.tag_base + epoch + 1u;
+  u64 *rows = ctx.rows + (size_t)(epoch & 1u) * kRowWords * kRowStride;
+  u64 *groups = ctx.groups + (size_t)(epoch & 1u) * kRowWords * kGroupStride;
+  if (lane < NS)
+    put_value(rows, kRowStride, 2 * lane, blockIdx.x, tag, sums[lane]);
+  else if (lane == kSums)
+    put_value(rows, kRowStride, 2 * kSums, blockIdx.x, tag, sums[kSums]);
+
+  double pv[NS], pmx;
+  if (blockIdx.x % kGroup == 0) {  // group leader (workgroup-uniform branch)
+    const int m = grp * kGroup + lane;
+    if (!gather_row<NS>(ctx, rows + m, kRowStride, tag, /*probe=*/false, lane < kGroup && m < G, pv, pmx)) {
+      *s_abort = 1;
+      return false;
+    }
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      const double t = row_reduce_to_last<OpSum>(pv[k]);
+      if (lane == kGroup - 1) put_value(groups, kGroupStride, 2 * k, grp, tag, t);
+    }
+    const double t = row_reduce_to_last<OpMax>(pmx);
+    if (lane == kGroup - 1) put_value(groups, kGroupStride, 2 * kSums, grp, tag, t);
+  }
   RSTAMP(2);
-  if (__any(failed)) {
+  if (!gather_row<NS>(ctx, groups + lane, kGroupStride, tag, /*probe=*/true, lane < ngrp, pv, pmx)) {
     *s_abort = 1;
     return false;
   }
 #pragma unroll
   for (int k = 0; k < NS; ++k) {
-    const double t = wave_reduce_to_last<OpSum>(pv[k]);
-    if (lane == kWave - 1) sums[k] = t;
+    const double t = row_reduce_to_last<OpSum>(pv[k]);
+    if (lane == kGroup - 1) sums[k] = t;
   }
   {
-    const double t = wave_reduce_to_last<OpMax>(pmx);
-    if (lane == kWave - 1) sums[kSums] = t;
+    const double t = row_reduce_to_last<OpMax>(pmx);
+    if (lane == kGroup - 1) sums[kSums] = t;
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -483,7 +520,7 @@ struct RWorkspace {
   static constexpr size_t kMachineBytes = 4096;
   static constexpr size_t off_machine = sizeof(ResidentCtl);
   static constexpr size_t off_rows = off_machine + kMachineBytes;
-  static constexpr size_t rows_bytes = sizeof(u64) * 2 * (size_t)kRowWords * kRowStride;
+  static constexpr size_t rows_bytes = sizeof(u64) * 2 * (size_t)kRowWords * (kRowStride + 16);  // rows + group rows
   unsigned tag_base = 0;
   FitStats stats{};
 
@@ -550,6 +587,7 @@ int resident_attempt(const StreamFitArgs &a, RWorkspace &ws, bool *retry_exact, 
   c.x = a.d_x;
   c.ctl = reinterpret_cast<ResidentCtl *>(ws.d_block);
   c.rows = reinterpret_cast<u64 *>(ws.d_block + RWorkspace::off_rows);
+  c.groups = c.rows + 2 * (size_t)kRowWords * kRowStride;
   c.machine0 = ws.d_block + RWorkspace::off_machine;
   c.mbox = ws.d_mbox;
   c.n = a.n;

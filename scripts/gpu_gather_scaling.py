@@ -5,7 +5,7 @@ import numpy as np, torch
 import brdf_amd
 from brdf_amd import synth
 dev = torch.device("cuda:0")
-names_res = ["-", "sweep+reduce", "publish+gather", "fold", "step+build"]
+names_res = ["-", "sweep+reduce", "level1", "level2+fold", "step+build"]
 for n in [1024, 8192, 32768, 65536, 131072, 262144, 1_000_000]:
     angles, x, _ = synth.make_single(2, n)
     a = torch.from_numpy(angles).to(dev); xd = torch.from_numpy(x).to(dev)
