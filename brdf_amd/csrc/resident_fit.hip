@@ -78,6 +78,28 @@ __device__ __forceinline__ void put_value(u64 *rows, int stride, int word, int c
 __device__ __forceinline__ u64 get_granule(const u64 *g) { return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double join_halves(u64 lo, u64 hi) { return __longlong_as_double((long long)((lo & 0xffffffffull) | (hi << 32))); }
 
+// The sweeps of this kernel are bound by fp64 issue, not by memory, so the accumulations are written as fused
+// multiply-adds (one instruction and one rounding instead of two; the library is otherwise built with
+// -ffp-contract=off so that lm_machine.h performs the reference's operations one by one).
+__device__ __forceinline__ void acc_normal_eq_fma(const double *j, double e, double *jtj6, double *jte3) {
+  jtj6[0] = fma(j[0], j[0], jtj6[0]);
+  jtj6[1] = fma(j[0], j[1], jtj6[1]);
+  jtj6[2] = fma(j[1], j[1], jtj6[2]);
+  jtj6[3] = fma(j[0], j[2], jtj6[3]);
+  jtj6[4] = fma(j[1], j[2], jtj6[4]);
+  jtj6[5] = fma(j[2], j[2], jtj6[5]);
+  jte3[0] = fma(j[0], e, jte3[0]);
+  jte3[1] = fma(j[1], e, jte3[1]);
+  jte3[2] = fma(j[2], e, jte3[2]);
+}
+// x / d given r = RN(1/d): RN(x*r) followed by one correction step is the correctly rounded quotient (Markstein's
+// theorem; the operands here are normal numbers) -- 3 instructions instead of the ~15 of a full fp64 division, for a
+// divisor that is the same for every sample of a pass (||Dp||^2, lm_core.c:763)
+__device__ __forceinline__ double div_by(double x, double d, double r) {
+  const double q = x * r;
+  return fma(fma(-q, d, x), r, q);
+}
+
 #ifdef BRDF_STAMPS
 #define RSTAMP(i) do { const long long now_ = clock64(); st_[i] += now_ - last_; last_ = now_; } while (0)
 #else
@@ -371,6 +393,7 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
 
     if constexpr (METHOD == 0) {  // commit what the machine decided about the previous trial (speculative protocol)
       if (sm.h.req.sel_j != cur_sel_j) {  // adopt the Broyden update J += ((wrk - hx - J Dp)/||Dp||^2) Dp^T, lm_core.c:760-766
+        const double rinv = 1.0 / dp_prev[kM];
 #pragma unroll
         for (int k = 0; k < kRSpt; ++k) if (k < nk) {
           const int s = k * kRWorkers + wt;
@@ -378,7 +401,7 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
           double t = 0.0;
 #pragma unroll
           for (int l = 0; l < kM; ++l) t += jo[l] * dp_prev[l];
-          t = (wrk[k] - hx[k] - t) / dp_prev[kM];
+          t = div_by(wrk[k] - hx[k] - t, dp_prev[kM], rinv);
 #pragma unroll
           for (int j = 0; j < kM; ++j) jl[j * kRCap + s] = jo[j] + t * dp_prev[j];
         }
@@ -401,7 +424,7 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
       for (int k = 0; k < kRSpt; ++k) if (k < nk) {
         const double f = model_value<MODEL, FAST>(u, s0[k], pq[k]);
         const double e = (okm >> k & 1u) ? sx[k] - f : 0.0;
-        acc[0] += e * e;
+        acc[0] = fma(e, e, acc[0]);
         mx = fmax(mx, fabs(e));
       }
       worker_reduce<1>(acc, mx, red, sums);
@@ -411,7 +434,7 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
       for (int k = 0; k < kRSpt; ++k) if (k < nk) {
         const double f = model_value<MODEL, FAST>(u, s0[k], pq[k]);
         const double t = (okm >> k & 1u) ? (sx[k] - f) / u.scal : 0.0;
-        acc[0] += t * t;
+        acc[0] = fma(t, t, acc[0]);
       }
       worker_reduce<1>(acc, mx, red, sums);
       break;
@@ -422,7 +445,7 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
         for (int j = 0; j < kMaxCand; ++j)
           if (j < u.ncand) {
             const double e = (okm >> k & 1u) ? sx[k] - model_value_k<MODEL, FAST>(u, j, s0[k], pq[k]) : 0.0;
-            acc[j] += e * e;
+            acc[j] = fma(e, e, acc[j]);
           }
       }
       worker_reduce<kMaxCand>(acc, mx, red, sums);
@@ -434,8 +457,8 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
         model_fd_row<MODEL, FAST>(u, s0[k], pq[k], true, f0, 0.0, false, j);
         double e = sx[k] - f0;
         if (!(okm >> k & 1u)) e = j[0] = j[1] = j[2] = 0.0;
-        acc_normal_eq(j, e, acc, acc + kNL);
-        acc[kNL + kM] += e * e;
+        acc_normal_eq_fma(j, e, acc, acc + kNL);
+        acc[kNL + kM] = fma(e, e, acc[kNL + kM]);
       }
       worker_reduce<SumLayout<kM>::JAC>(acc, mx, red, sums);
       break;
@@ -445,7 +468,7 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
         for (int k = 0; k < kRSpt; ++k) if (k < nk) {
           hx[k] = model_value<MODEL, FAST>(u, s0[k], pq[k]);
           const double e = (okm >> k & 1u) ? sx[k] - hx[k] : 0.0;
-          acc[0] += e * e;
+          acc[0] = fma(e, e, acc[0]);
         }
       }
       worker_reduce<1>(acc, mx, red, sums);
@@ -462,7 +485,7 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
           jl[s] = j[0];
           jl[kRCap + s] = j[1];
           jl[2 * kRCap + s] = j[2];
-          acc_normal_eq(j, e, acc, acc + kNL);
+          acc_normal_eq_fma(j, e, acc, acc + kNL);
         }
       }
       worker_reduce<SumLayout<kM>::DIF_JAC>(acc, mx, red, sums);
@@ -470,21 +493,26 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
     case RQ_DIF_TRIAL:  // speculative protocol: the Broyden-updated row is formed for the sums only; J itself is
                         // updated (from wrk, hx) at the top of the next pass if the machine adopts it
       if constexpr (METHOD == 0) {
+        const double rinv = 1.0 / u.dp_l2;
 #pragma unroll
         for (int k = 0; k < kRSpt; ++k) if (k < nk) {
           const int s = k * kRWorkers + wt;
           const double w = model_value_q<MODEL, FAST>(u, s0[k], pq[k]);
           const double jo[kM] = {jl[s], jl[kRCap + s], jl[2 * kRCap + s]};
-          double jn[kM];
-          broyden_row(jo, w, hx[k], u.dp, u.dp_l2, jn);
+          double t = 0.0, jn[kM];  // broyden_row() with the division by ||Dp||^2 done by div_by()
+#pragma unroll
+          for (int l = 0; l < kM; ++l) t += jo[l] * u.dp[l];
+          t = div_by(w - hx[k] - t, u.dp_l2, rinv);
+#pragma unroll
+          for (int j = 0; j < kM; ++j) jn[j] = jo[j] + t * u.dp[j];
           double en = sx[k] - w, eo = sx[k] - hx[k];
           if (!(okm >> k & 1u)) en = eo = jn[0] = jn[1] = jn[2] = 0.0;
           wrk[k] = w;
-          acc[0] += en * en;
-          acc_normal_eq(jn, en, acc + 1, acc + 1 + kNL);
-          acc[1 + kNL + kM + 0] += jn[0] * eo;
-          acc[1 + kNL + kM + 1] += jn[1] * eo;
-          acc[1 + kNL + kM + 2] += jn[2] * eo;
+          acc[0] = fma(en, en, acc[0]);
+          acc_normal_eq_fma(jn, en, acc + 1, acc + 1 + kNL);
+          acc[1 + kNL + kM + 0] = fma(jn[0], eo, acc[1 + kNL + kM + 0]);
+          acc[1 + kNL + kM + 1] = fma(jn[1], eo, acc[1 + kNL + kM + 1]);
+          acc[1 + kNL + kM + 2] = fma(jn[2], eo, acc[1 + kNL + kM + 2]);
         }
       }
       worker_reduce<SumLayout<kM>::DIF_TRIAL>(acc, mx, red, sums);
@@ -654,14 +682,11 @@ FitStats resident_fit_last_stats() { return g_rws.stats; }
 
 // returns true if the resident path handled the fit (*ret is then the solver's return value)
 bool resident_fit_try(const StreamFitArgs &a, int *ret) {
-  // Default: dlevmar_dif only.  Measured on MI355X, 1M-sample Ward fit (bench.py, 20 fits): 16.6 us per dlevmar_dif
-  // pass against 19.7 us for the launch chain (the secant Jacobian no longer travels through HBM), but 12.2 us per
-  // dlevmar_bc_dif pass against 11.3 us: the in-launch all-gather of 256 rows costs ~6 us where the kernel boundary
-  // + partial-row reload cost ~4 us, and bc_dif has no per-sample state to save.
-  // BRDF_HIP_RESIDENT=0: always the launch chain; =1: resident for both entry points.
+  // Default for every single fit that fits the chip.  Measured on MI355X, 1M-sample Ward fit: 14.3 us per dlevmar_dif
+  // pass against 19.7 us for the launch chain (the secant Jacobian no longer travels through HBM) and 10.7 us per
+  // dlevmar_bc_dif pass against 11.3 us.  BRDF_HIP_RESIDENT=0: always the launch chain.
   const char *e = getenv("BRDF_HIP_RESIDENT");
   if (e && e[0] == '0') return false;
-  if (a.method != 0 && !(e && e[0] == '1')) return false;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return false;
   RWorkspace &ws = g_rws;

@@ -303,14 +303,11 @@ def test_device_generator_matches_host_generator(gpu):
 def test_resident_and_launch_chain_regimes(gpu, monkeypatch):
     """A single fit that fits the chip (n <= #CUs * 4096) can run in ONE launch with its samples resident in
     registers/LDS (resident_fit.hip, passes separated by an in-launch all-gather of tagged granules) or as the launch
-    chain (stream_fit.hip, one launch per pass).  Default: resident for dlevmar_dif, chain for dlevmar_bc_dif;
-    BRDF_HIP_RESIDENT=1 / =0 force one regime for both.  Same machines, same parity bar, everything covered."""
+    chain (stream_fit.hip, one launch per pass; BRDF_HIP_RESIDENT=0, and any fit too large for the chip).  Same machines,
+    same parity bar, both covered."""
     torch, brdf_amd, dev = gpu
-    for env in ("1", "0", ""):
-        if env:
-            monkeypatch.setenv("BRDF_HIP_RESIDENT", env)
-        else:
-            monkeypatch.delenv("BRDF_HIP_RESIDENT")
+    for env in ("1", "0"):
+        monkeypatch.setenv("BRDF_HIP_RESIDENT", env)
         for model, n in ((2, 100000), (1, 5000), (0, 300)):
             angles, x, _ = synth.make_single(model, n)
             for method in (0, 1):
@@ -318,7 +315,7 @@ def test_resident_and_launch_chain_regimes(gpu, monkeypatch):
                                                 synth.LB, synth.UB)
                 _check(_dev_fit(gpu, method, model, angles, x), p_ref, info_ref)
                 st = brdf_amd.last_fit_stats()
-                assert (st["launches"] == 1) == (env == "1" or (env == "" and method == 0)), st
+                assert (st["launches"] == 1) == (env == "1"), st
 
 
 def test_diagonal_scaling_and_nan_input(gpu):
