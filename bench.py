@@ -186,10 +186,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        # one more event pair around every fit: the kernel launches of ONE fit without the host gap between two fits
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
         t0 = time.perf_counter()
         ev0.record()  # same (current) stream the C ABI launches the pass kernels on
         for s in range(steps):
+            evs[s][0].record()
             r = brdf_amd.fit_single(method, MODEL, a_dev, x_dev, p0, lb=lb, ub=ub, itmax=itmax, opts=opts)
+            evs[s][1].record()
             if r.ret < 0:
                 raise RuntimeError(f"fit failed: {brdf_amd.last_error()}")
             res_np[s, :3] = r.p
@@ -210,8 +214,9 @@ def main():
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
         ev_ms = ev0.elapsed_time(ev1)
+        fit_ms = sum(a.elapsed_time(b) for a, b in evs)
         stat = torch.tensor([wall, float(results[:, 10].sum().item()) * N_SAMPLES, ev_ms, float(passes), float(jac), dev_us,
-                             float(launches)],
+                             float(launches), fit_ms],
                             dtype=torch.float64, device=coll_dev)
         if world > 1:
             allstat = [torch.empty_like(stat) for _ in range(world)]
@@ -236,9 +241,12 @@ def main():
             "nfev": float(r0[0, 10]), "iters": float(r0[0, 8]), "passes_per_step": float(allstat[0, 3]) / args.steps,
             "event_ms_rank0": float(allstat[0, 2]), "device_us_per_step": float(allstat[0, 5]) / args.steps,
             "p": [float(v) for v in r0[0, :3]], "sumsq": float(r0[0, 4]),
-            # HIP-event time of the timed region / ALL launches of the pass kernel in it (the passes plus the few
-            # run-ahead launches per fit that find it finished): the population rocprofv3 averages over
-            "avg_launch_us": 1e3 * float(allstat[0, 2]) / max(1.0, float(allstat[0, 6])),
+            # HIP-event time of the fits (one event pair per fit, summed over the timed region) / ALL launches of the
+            # pass kernel in them (launch chain: the passes plus the few run-ahead launches per fit that find it finished):
+            # the population rocprofv3 averages over.  region_us_per_launch = the whole timed region / launches, i.e.
+            # with the host's gaps between two fits
+            "avg_launch_us": 1e3 * float(allstat[0, 7]) / max(1.0, float(allstat[0, 6])),
+            "region_us_per_launch": 1e3 * float(allstat[0, 2]) / max(1.0, float(allstat[0, 6])),
             "launches_per_step": float(allstat[0, 6]) / args.steps,
             # device clock (s_memrealtime) from the first to the finishing pass / passes: sweeping launches only
             "avg_sweeping_launch_us": float(allstat[0, 5]) / max(1.0, float(allstat[0, 3])),
@@ -269,14 +277,15 @@ def main():
         kernel_desc = ("brdf::resident_fit_kernel<2,0,true> (one launch per fit: samples + secant Jacobian resident in registers/LDS, "
                        "model eval + residual + Broyden + JtJ/Jte fused per LM evaluation, in-launch all-gather between evaluations)")
         note = ("algorithmic bytes = 32 B per sample per LM evaluation (Ward: 3 planes + measurement, fp64) x 1e6 samples x the "
-                "launch's evaluations (sweeps_per_launch); avg launch = HIP-event time of the timed region / launches (= fits; "
-                "includes the per-fit upload, the in-launch exchanges and the serial LM steps); avg_sweeping_launch_us = device clock "
+                "launch's evaluations (sweeps_per_launch); avg launch = HIP-event time around each fit's launch (its 4 KB upload "
+                "included), averaged over the timed region's fits -- in-launch exchanges and serial LM steps are part of the launch; "
+                "region_us_per_launch adds the host's gap between two fits; avg_sweeping_launch_us = device clock "
                 "per evaluation.  traffic = HBM-side bytes per launch from rocprofv3 FETCH_SIZE (x2 gfx950 correction, calibrated) + "
                 "WRITE_SIZE, profiles/r01_traffic.json: the samples are read ONCE per fit, so the measured traffic is ~1/sweeps of the "
                 "algorithmic bytes -- the launch is bound by the exchange + LM step latency and fp64 issue, not by HBM (DESIGN.md)")
     else:
         kernel_desc = "brdf::stream_pass<2,0,true> (fused model eval + residual + Broyden + JtJ/Jte sweep, one launch per LM evaluation)"
-        note = ("avg launch = HIP-event time of the timed region / launches of the pass kernel in it (passes + run-ahead "
+        note = ("avg launch = HIP-event time of the fits / launches of the pass kernel in them (passes + run-ahead "
                 "launches that return at once; includes inter-launch gaps, the per-fit upload and the in-kernel LM step); "
                 "avg_sweeping_launch_us = device clock over the passes only; 32 B per sample-pass for Ward (3 planes + measurement, fp64); traffic = "
                 "HBM-side bytes per launch from rocprofv3 FETCH_SIZE (x2 gfx950 correction, calibrated) + WRITE_SIZE, "
@@ -295,7 +304,8 @@ def main():
                      "traffic": traffic,
                      "kernel": kernel_desc, "regime": "resident" if resident else "launch chain",
                      "algorithmic_bytes_per_launch": bytes_per_launch, "sweeps_per_launch": sweeps_per_launch,
-                     "avg_launch_us": head["avg_launch_us"], "avg_sweeping_launch_us": head["avg_sweeping_launch_us"],
+                     "avg_launch_us": head["avg_launch_us"], "region_us_per_launch": head["region_us_per_launch"],
+                     "avg_sweeping_launch_us": head["avg_sweeping_launch_us"],
                      "launches_per_step": head["launches_per_step"], "note": note},
         "fitted_params": head["p"], "sumsq": head["sumsq"],
         "bc_dif": {k: out["bc_dif"][k] for k in ("value", "ms_per_step", "nfev", "iters", "passes_per_step", "launches_per_step", "avg_launch_us",

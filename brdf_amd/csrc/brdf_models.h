@@ -134,7 +134,8 @@ struct PassUniforms {
 
   // only what the request kind reads is computed (each lin()/nl() hides an fp64 division or two, and on the
   // device this runs on a single lane between two passes)
-  LM_HD void build(const Request<kM> &r) {
+  // need_base = false: the caller keeps f(p) per sample (resident regime), so a dif trial pass evaluates f at q only
+  LM_HD void build(const Request<kM> &r, bool need_base = true) {
     ncand = 0;
     if (r.kind == RQ_EVAL_MULTI) {
       ncand = r.nk;
@@ -145,7 +146,7 @@ struct PassUniforms {
         }
       return;
     }
-    if (r.kind != RQ_DIF_UPDATE) {
+    if (r.kind != RQ_DIF_UPDATE && (need_base || r.kind != RQ_DIF_TRIAL)) {
       l0 = Mdl::lin(r.p);
       n0 = Mdl::nl(r.p);
     }

@@ -324,7 +324,7 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
         dp_prev[kM] = su.dp_l2;
       }
       sm.template step<true>(sums, sums[kSums]);
-      if (sm.h.req.kind != RQ_DONE) su.build(sm.h.req);
+      if (sm.h.req.kind != RQ_DONE) su.build(sm.h.req, /*need_base=*/false);
       __syncthreads();  // B: the next request and its uniforms are in LDS
       RSTAMP(4);
     }

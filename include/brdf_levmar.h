@@ -140,7 +140,8 @@ int brdf_hip_last_fit_stats(long long *passes, long long *jac_passes, long long 
 long long brdf_hip_last_fit_launches(void);
 
 /* only meaningful in diagnostic builds (-DBRDF_STAMPS): shader cycles spent per section of the pass
- * kernel (load state, fold, step, uniforms, persist, sweep, reduce), summed over the fit's passes. */
+ * kernel (launch chain: load state, fold, step, uniforms, persist, sweep, reduce; resident regime: -, sweep +
+ * reduce, level-1 gather, level-2 gather + fold, step + uniforms), summed over the fit's passes. */
 int brdf_hip_last_fit_stamps(long long *out8);
 
 #ifdef __cplusplus
