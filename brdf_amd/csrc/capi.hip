@@ -308,6 +308,15 @@ int brdf_hip_synth_dev(int model, unsigned long long seed, long long first, int 
   return synth_enqueue(model, seed, first, count, n, d_truth, d_angles, d_x, static_cast<hipStream_t>(stream));
 }
 
+int brdf_hip_cosines_dev(const double *d_vertices, const int *d_faces, const double *d_face_normals, const int *d_surfels,
+                         long long S, const double *leds, int L, const double *view_origin, int rv_mode, double *d_angles,
+                         void *stream) {
+  return cosines_run(d_vertices, d_faces, d_face_normals, d_surfels, S, leds, L, view_origin, rv_mode, d_angles,
+                     static_cast<hipStream_t>(stream));
+}
+
+void brdf_hip_led_table(double *leds16x3) { led_table(leds16x3); }
+
 int brdf_hip_device_count(void) {
   int c = 0;
   if (hipGetDeviceCount(&c) != hipSuccess) return 0;

@@ -82,6 +82,11 @@ FitStats stream_fit_last_stats();
 bool resident_fit_try(const StreamFitArgs &a, int *ret);
 FitStats resident_fit_last_stats();
 
+// vectors -> cosines (cosines.hip)
+int cosines_run(const double *d_vertices, const int *d_faces, const double *d_normals, const int *d_surfels, long long S,
+                const double *leds, int L, const double *view, int rv_mode, double *d_angles, hipStream_t stream);
+void led_table(double *out16x3);
+
 bool brdf_fast_path_enabled();  // false when BRDF_HIP_EXACT_POW=1
 int pg_candidates();            // BRDF_HIP_PG_MULTI (default kMaxCand)
 void set_error(const char *fmt, ...);

@@ -97,6 +97,38 @@ def model_eval(model: int, angles, p):
     return hx
 
 
+def led_table() -> np.ndarray:
+    """CBRDFdata::InitLEDs (brdfdata.cpp:683-752): the capture rig's 16 LED positions, [16, 3]."""
+    out = np.zeros(48)
+    lib.brdf_hip_led_table(_dptr(out))
+    return out.reshape(16, 3)
+
+
+def cosines(vertices, faces, face_normals, leds, view_origin, *, surfels=None, rv_mode: int = 0):
+    """vectors -> cosines on the device (GetCosLN / GetCosNH / GetCosRV, brdfdata.cpp:799-943) for a batch of surfels.
+    vertices [nv,3] float64, faces [nf,3] int32, face_normals [nf,3] float64: CUDA tensors; surfels: CUDA int32 [S]
+    (face index per surfel) or None (surfel s = face s); leds [L,3], view_origin [3]: host.  Returns CUDA float64
+    [S, 3, L] -- the batched fitter's `angles` layout."""
+    import torch
+    vertices, faces, face_normals = vertices.contiguous(), faces.contiguous(), face_normals.contiguous()
+    assert vertices.dtype == torch.float64 and face_normals.dtype == torch.float64 and faces.dtype == torch.int32
+    if surfels is not None:
+        surfels = surfels.contiguous()
+        assert surfels.dtype == torch.int32
+    S = int(surfels.numel()) if surfels is not None else int(faces.shape[0])
+    la = np.ascontiguousarray(leds, dtype=np.float64).reshape(-1, 3)
+    L = la.shape[0]
+    va = _f64(view_origin, 3)
+    out = torch.empty((S, 3, L), dtype=torch.float64, device=vertices.device)
+    with torch.cuda.device(vertices.device):
+        rc = lib.brdf_hip_cosines_dev(vertices.data_ptr(), faces.data_ptr(), face_normals.data_ptr(),
+                                      surfels.data_ptr() if surfels is not None else None, S, _dptr(la), L, _dptr(va), rv_mode,
+                                      out.data_ptr(), _stream_handle(torch))
+    if rc != 0:
+        raise RuntimeError(f"brdf_hip_cosines_dev failed: {last_error()}")
+    return out
+
+
 def host_dlevmar(method: int, model: int, angles: np.ndarray, x: np.ndarray, p0, *, lb=None, ub=None, dscl=None,
                  itmax=100, opts=None, want_covar=False) -> FitResult:
     """The drop-in call exactly as brdfdata.cpp:1058/1119 makes it: HOST arrays, a BRDFFunc-style callback

@@ -127,6 +127,23 @@ int brdf_hip_model_eval_dev(int model, const double *d_angles, int n, const doub
 int brdf_hip_synth_dev(int model, unsigned long long seed, long long first, int count, int n,
                        const double *d_truth, double *d_angles, double *d_x, void *stream);
 
+/* ---- the step before the fit: vectors -> cosines ---------------------------- */
+/* Replaces CBRDFdata::GetCosLN / GetCosNH / GetCosRV (brdfdata.cpp:859-899, :902-943, :799-857), which the reference
+ * evaluates per pixel / per face and per light on the host.  One launch fills, for S surfels, the three cosine planes
+ * in the batched fitter's layout d_angles[S][3][L] (struct extraData's SoA planes, brdfdata.cpp:962-966, per surfel;
+ * for L = 16 this is exactly what brdf_hip_fit_batch_dev reads with n = 16).
+ *   d_vertices[nv][3], d_faces[nf][3] (vertex indices), d_face_normals[nf][3]: device, row-major (m_vertices, m_faces,
+ *   face_normals); d_surfels[S]: face index of every surfel (the pixel map's entries, brdfdata.cpp:1197), or NULL for
+ *   surfel s = face s; leds[L][3], view_origin[3]: HOST (m_led, m_p), L <= 64.
+ *   rv_mode 0: GetCosRV's arithmetic exactly as written, including its slips (:835 builds the light vector from the
+ *   centroid's x three times, :849 returns R.P); rv_mode 1: cos(R.V) of the geometry its comments describe.
+ * Returns 0, or LM_ERROR with a message in brdf_hip_last_error(). */
+int brdf_hip_cosines_dev(const double *d_vertices, const int *d_faces, const double *d_face_normals, const int *d_surfels,
+                         long long S, const double *leds, int L, const double *view_origin, int rv_mode, double *d_angles,
+                         void *stream);
+/* CBRDFdata::InitLEDs (brdfdata.cpp:683-752): the capture rig's 16 LED positions, row-major [16][3] (host) */
+void brdf_hip_led_table(double *leds16x3);
+
 /* ---- diagnostics ----------------------------------------------------------------------------------- */
 int brdf_hip_device_count(void);
 const char *brdf_hip_last_error(void);

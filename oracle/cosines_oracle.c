@@ -1,0 +1,83 @@
+/* cosines_oracle.c -- TEST INFRASTRUCTURE ONLY: CPU restatement of the reference's vectors -> cosines step.
+ *
+ * PARITY UNPINNED: the reference computes these values with Eigen and OpenCV types (brdfdata.cpp:799-943), which
+ * cannot be compiled in this image, and none of its files holds an expected value for them.  This file restates
+ * the formulas operation by operation; it is checked against an independent numpy restatement
+ * (tests/test_cosines.py), not against the reference itself.
+ *
+ *   orc_cosines    CBRDFdata::GetCosLN (brdfdata.cpp:859-899), GetCosNH (:902-943), GetCosRV (:799-857)
+ *   orc_led_table  CBRDFdata::InitLEDs (brdfdata.cpp:683-752)
+ */
+#include <math.h>
+#include <stddef.h>
+
+static double dot3(const double *a, const double *b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+
+/* Eigen's normalize(): if (squaredNorm() > 0) v /= sqrt(squaredNorm()) */
+static void normalize3(double *v) {
+  const double z = dot3(v, v);
+  if (z > 0.0) {
+    const double n = sqrt(z);
+    v[0] /= n;
+    v[1] /= n;
+    v[2] /= n;
+  }
+}
+
+/* angles[S][3][L]; surfels == NULL: surfel s = face s.  rv_mode 0: GetCosRV as written (its light vector uses the
+ * centroid's x three times, :835, and it returns R.P, :849); rv_mode 1: cos(R.V) of the geometry in its comments. */
+void orc_cosines(const double *vertices, const int *faces, const double *normals, const int *surfels, long long S,
+                 const double *leds, int L, const double *view, int rv_mode, double *angles) {
+  for (long long s = 0; s < S; ++s) {
+    const int f = surfels ? surfels[s] : (int)s;
+    double c[3];
+    for (int k = 0; k < 3; ++k) { /* brdfdata.cpp:816-827 */
+      double t = 0.0;
+      for (int j = 0; j < 3; ++j) t += vertices[3 * (size_t)faces[3 * (size_t)f + j] + k];
+      c[k] = t / 3.0;
+    }
+    const double *nrm = normals + 3 * (size_t)f;
+    for (int i = 0; i < L; ++i) {
+      const double *l = leds + 3 * i;
+      double ld[3] = {l[0] - c[0], l[1] - c[1], l[2] - c[2]}; /* :886-895 */
+      normalize3(ld);
+      angles[((size_t)s * 3 + 0) * L + i] = dot3(ld, nrm);
+
+      double h[3] = {l[0] - 2 * c[0] + view[0], l[1] - 2 * c[1] + view[1], l[2] - 2 * c[2] + view[2]}; /* :930-939 */
+      normalize3(h);
+      angles[((size_t)s * 3 + 1) * L + i] = dot3(h, nrm);
+
+      double md[3], vd[3] = {view[0] - c[0], view[1] - c[1], view[2] - c[2]}; /* :828-853 */
+      if (rv_mode == 0) {
+        md[0] = c[0] - l[0];
+        md[1] = c[0] - l[1];
+        md[2] = c[0] - l[2];
+      } else {
+        md[0] = c[0] - l[0];
+        md[1] = c[1] - l[1];
+        md[2] = c[2] - l[2];
+        normalize3(vd);
+      }
+      normalize3(md);
+      const double sf = dot3(nrm, md);
+      const double P[3] = {sf * nrm[0], sf * nrm[1], sf * nrm[2]};
+      const double R[3] = {md[0] - 2 * P[0], md[1] - 2 * P[1], md[2] - 2 * P[2]};
+      angles[((size_t)s * 3 + 2) * L + i] = (rv_mode == 0) ? dot3(R, P) : dot3(R, vd);
+    }
+  }
+}
+
+void orc_led_table(double *out) { /* brdfdata.cpp:695-752, written out entry by entry like the reference */
+  const double x = 303.5, min_y = -157.1, max_y = -2.3, min_z = 555.3, max_z = 645.8;
+  const double y_step = (max_y - min_y) / 3, z_step = (max_z - min_z) / 3;
+  const double yz[16][2] = {
+      {max_y, min_z},          {max_y - y_step, min_z},          {min_y + y_step, min_z},          {min_y, min_z},
+      {min_y, min_z + z_step}, {min_y + y_step, min_z + z_step}, {max_y - y_step, min_z + z_step}, {max_y, min_z + z_step},
+      {max_y, max_z - z_step}, {max_y - y_step, max_z - z_step}, {min_y + y_step, max_z - z_step}, {min_y, max_z - z_step},
+      {min_y, max_z},          {min_y + y_step, max_z},          {max_y - y_step, max_z},          {max_y, max_z}};
+  for (int i = 0; i < 16; ++i) {
+    out[3 * i] = x;
+    out[3 * i + 1] = yz[i][0];
+    out[3 * i + 2] = yz[i][1];
+  }
+}

@@ -65,3 +65,23 @@ def model_values(model: int, angles, p):
 def rel_err(p, p_ref):
     p, p_ref = np.asarray(p), np.asarray(p_ref)
     return float(np.max(np.abs(p - p_ref) / np.maximum(np.abs(p_ref), 1e-12)))
+
+
+def cosines(vertices, faces, normals, leds, view, surfels=None, rv_mode=0):
+    """oracle/cosines_oracle.c: angles[S][3][L] for the surfels (face indices; None = every face in order)"""
+    v, nr, ld, vw = f64(vertices), f64(normals), f64(leds), f64(view)
+    fc = np.ascontiguousarray(np.asarray(faces, dtype=np.int32).reshape(-1))
+    sf = None if surfels is None else np.ascontiguousarray(np.asarray(surfels, dtype=np.int32))
+    S = fc.size // 3 if sf is None else sf.size
+    L = ld.size // 3
+    out = np.zeros((S, 3, L))
+    IP = C.POINTER(C.c_int)
+    orc.orc_cosines(ptr(v), fc.ctypes.data_as(IP), ptr(nr), None if sf is None else sf.ctypes.data_as(IP), C.c_longlong(S),
+                    ptr(ld), L, ptr(vw), rv_mode, ptr(out))
+    return out
+
+
+def led_table():
+    out = np.zeros(48)
+    orc.orc_led_table(ptr(out))
+    return out.reshape(16, 3)

@@ -1,0 +1,133 @@
+"""Vectors -> cosines (brdfdata.cpp:799-943, LED table :683-752).
+
+PARITY UNPINNED: the reference computes these with Eigen/OpenCV types that cannot be built here and holds no expected
+values for them.  The CPU tests check the C restatement (oracle/cosines_oracle.c) against an independent numpy
+restatement of the same formulas; the GPU tests check the HIP kernel against the C restatement, bit for bit (both perform
+the same IEEE operations in the same order; the library is built with -ffp-contract=off)."""
+import numpy as np
+import pytest
+
+from tests import oracle_libs as L
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    import brdf_amd
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch, brdf_amd, torch.device("cuda:0")
+
+
+def make_mesh(nv=500, nf=900, seed=7):
+    rng = np.random.default_rng(seed)
+    vertices = rng.uniform(-80.0, 80.0, size=(nv, 3)) + np.array([0.0, -80.0, 60.0])
+    faces = np.stack([rng.permutation(nv)[:3] for _ in range(nf)]).astype(np.int32)
+    e1 = vertices[faces[:, 1]] - vertices[faces[:, 0]]
+    e2 = vertices[faces[:, 2]] - vertices[faces[:, 0]]
+    nrm = np.cross(e1, e2)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    view = np.array([310.0, -75.0, 700.0])
+    return vertices, faces, nrm, view
+
+
+def numpy_cosines(vertices, faces, nrm, leds, view, rv_mode):
+    c = vertices[faces].sum(axis=1) / 3.0                       # [nf,3]
+    def unit(v):
+        return v / np.sqrt((v * v).sum(axis=-1, keepdims=True))
+    ld = unit(leds[None, :, :] - c[:, None, :])                 # [nf,L,3]
+    cos_ln = (ld * nrm[:, None, :]).sum(-1)
+    h = unit(leds[None, :, :] - 2 * c[:, None, :] + view[None, None, :])
+    cos_nh = (h * nrm[:, None, :]).sum(-1)
+    if rv_mode == 0:
+        md = unit(c[:, None, 0:1] - leds[None, :, :])           # centroid x for all three components (brdfdata.cpp:835)
+    else:
+        md = unit(c[:, None, :] - leds[None, :, :])
+    sf = (nrm[:, None, :] * md).sum(-1, keepdims=True)
+    P = sf * nrm[:, None, :]
+    R = md - 2 * P
+    if rv_mode == 0:
+        cos_rv = (R * P).sum(-1)                                # R.P (brdfdata.cpp:849)
+    else:
+        cos_rv = (R * unit(view[None, :] - c)[:, None, :]).sum(-1)
+    return np.stack([cos_ln, cos_nh, cos_rv], axis=1)           # [nf,3,L]
+
+
+def test_led_table_is_the_rig_of_the_reference():
+    """InitLEDs, brdfdata.cpp:695-752: x = 303.5 for all; y/z on a 4 x 4 grid wired boustrophedon"""
+    t = L.led_table()
+    assert t.shape == (16, 3) and np.all(t[:, 0] == 303.5)
+    y0, y1, z0, z1 = -157.1, -2.3, 555.3, 645.8
+    assert t[0, 1] == y1 and t[0, 2] == z0 and t[3, 1] == y0 and t[4, 1] == y0 and t[7, 1] == y1
+    assert t[12, 1] == y0 and t[15, 1] == y1 and t[15, 2] == z1 and t[12, 2] == z1
+    assert np.allclose(np.unique(np.round(t[:, 2], 9)), np.round([z0, z0 + (z1 - z0) / 3, z1 - (z1 - z0) / 3, z1], 9))
+    assert len({(round(a, 9), round(b, 9)) for a, b in t[:, 1:]}) == 16  # sixteen distinct positions
+
+
+@pytest.mark.parametrize("rv_mode", [0, 1])
+def test_c_restatement_against_numpy_restatement(rv_mode):
+    vertices, faces, nrm, view = make_mesh()
+    leds = L.led_table()
+    got = L.cosines(vertices, faces, nrm, leds, view, rv_mode=rv_mode)
+    want = numpy_cosines(vertices, faces, nrm, leds, view, rv_mode)
+    assert got.shape == want.shape == (faces.shape[0], 3, 16)
+    assert np.max(np.abs(got - want)) <= 4e-15  # numpy sums/divides in another order: a few ulp of values <= 1
+    assert np.all(np.abs(got[:, :2, :]) <= 1.0 + 1e-15)  # plain cosines of unit vectors
+    if rv_mode == 1:
+        assert np.all(np.abs(got[:, 2, :]) <= 1.0 + 1e-15)
+
+
+def test_surfel_indirection_and_ragged_batches():
+    vertices, faces, nrm, view = make_mesh()
+    leds = L.led_table()[:5]  # L need not be 16
+    surfels = np.array([3, 3, 899, 0, 17], dtype=np.int32)  # repeated and unordered faces (a pixel map's entries)
+    got = L.cosines(vertices, faces, nrm, leds, view, surfels=surfels)
+    full = L.cosines(vertices, faces, nrm, leds, view)
+    assert got.shape == (5, 3, 5) and np.array_equal(got, full[surfels])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rv_mode", [0, 1])
+def test_device_cosines_bit_exact(gpu, rv_mode):
+    torch, brdf_amd, dev = gpu
+    vertices, faces, nrm, view = make_mesh(nv=4000, nf=30011, seed=11)
+    leds = brdf_amd.led_table()
+    assert np.array_equal(leds, L.led_table())
+    tv, tf, tn = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (vertices, faces, nrm))
+    got = brdf_amd.cosines(tv, tf, tn, leds, view, rv_mode=rv_mode).cpu().numpy()
+    want = L.cosines(vertices, faces, nrm, leds, view, rv_mode=rv_mode)
+    assert np.array_equal(got, want)
+    surfels = np.random.default_rng(5).integers(0, faces.shape[0], size=1001).astype(np.int32)
+    got = brdf_amd.cosines(tv, tf, tn, leds[:7], view, surfels=torch.from_numpy(surfels).to(dev), rv_mode=rv_mode).cpu().numpy()
+    assert np.array_equal(got, L.cosines(vertices, faces, nrm, leds[:7], view, surfels=surfels, rv_mode=rv_mode))
+
+
+@pytest.mark.gpu
+def test_cosines_feed_the_batched_fitter(gpu):
+    """f1 -> the path: planes produced on the device go straight into brdf_hip_fit_batch_dev (n = 16 lights per
+    surfel, the application's own size); the result equals fitting the oracle's planes."""
+    torch, brdf_amd, dev = gpu
+    from brdf_amd import synth
+    vertices, faces, nrm, view = make_mesh(nv=300, nf=64, seed=3)
+    # orient the normals towards the rig so that the cosines are positive (a lit, visible surfel)
+    leds = brdf_amd.led_table()
+    c = vertices[faces].sum(axis=1) / 3.0
+    flip = ((leds.mean(axis=0)[None, :] - c) * nrm).sum(axis=1) < 0
+    nrm[flip] *= -1.0
+    tv, tf, tn = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (vertices, faces, nrm))
+    angles = brdf_amd.cosines(tv, tf, tn, leds, view, rv_mode=1)
+    ref_angles = L.cosines(vertices, faces, nrm, leds, view, rv_mode=1)
+    assert np.array_equal(angles.cpu().numpy(), ref_angles)
+    model, truth = 1, np.array(synth.TRUTH[1])
+    x = np.stack([L.model_values(model, np.abs(a), truth) for a in ref_angles])
+    pos = torch.abs(angles)
+    p0 = torch.tensor(synth.P0[model], dtype=torch.float64, device=dev).repeat(angles.shape[0], 1)
+    lb, ub = synth.bounds(model)
+    p, info, ret = brdf_amd.fit_batch(1, model, pos, torch.from_numpy(x).to(dev), p0, lb=lb, ub=ub, itmax=synth.ITMAX, opts=synth.OPTS)
+    p, info, ret = p.cpu().numpy(), info.cpu().numpy(), ret.cpu().numpy()
+    # n = 16 fits are ill-conditioned (SURVEY.md section 6 ii): same bar as the other tiny-fit tests -- the device must
+    # reach at least the objective the CPU restatement of levmar reaches from the same planes
+    for s in range(angles.shape[0]):
+        r, _, info_ref = L.brdf_fit("orc", 1, model, np.abs(ref_angles[s]), x[s], synth.P0[model], synth.ITMAX, synth.OPTS, lb, ub)
+        assert ret[s] >= 0 or r < 0
+        if r >= 0 and ret[s] >= 0:
+            assert info[s, 1] <= info_ref[1] * (1 + 1e-3) + 1e-20
