@@ -317,6 +317,15 @@ int brdf_hip_cosines_dev(const double *d_vertices, const int *d_faces, const dou
 
 void brdf_hip_led_table(double *leds16x3) { led_table(leds16x3); }
 
+int brdf_hip_fit_capture_dev(int model, const unsigned char *d_images, int L, int H, int W, const int *d_pixel_map,
+                             const double *d_vertices, const int *d_faces, const double *d_face_normals, int nf,
+                             const double *leds, const double *view_origin, int rv_mode, const double *p0, const double *lb,
+                             const double *ub, int itmax, const double *opts, double *d_brdf_surfaces, double *avg,
+                             long long *n_pixels, void *stream) {
+  return capture_fit_run(model, d_images, L, H, W, d_pixel_map, d_vertices, d_faces, d_face_normals, nf, leds, view_origin,
+                         rv_mode, p0, lb, ub, itmax, opts, d_brdf_surfaces, avg, n_pixels, static_cast<hipStream_t>(stream));
+}
+
 int brdf_hip_device_count(void) {
   int c = 0;
   if (hipGetDeviceCount(&c) != hipSuccess) return 0;

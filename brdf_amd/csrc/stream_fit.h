@@ -86,6 +86,11 @@ FitStats resident_fit_last_stats();
 int cosines_run(const double *d_vertices, const int *d_faces, const double *d_normals, const int *d_surfels, long long S,
                 const double *leds, int L, const double *view, int rv_mode, double *d_angles, hipStream_t stream);
 void led_table(double *out16x3);
+// the pixel loop of CalcBRDFEquation (capture_fit.hip)
+int capture_fit_run(int model, const unsigned char *d_images, int L, int H, int W, const int *d_pixel_map,
+                    const double *d_vertices, const int *d_faces, const double *d_normals, int nf, const double *leds,
+                    const double *view, int rv_mode, const double *p0, const double *lb, const double *ub, int itmax,
+                    const double *opts, double *d_brdf_surfaces, double *avg, long long *n_pixels, hipStream_t stream);
 
 bool brdf_fast_path_enabled();  // false when BRDF_HIP_EXACT_POW=1
 int pg_candidates();            // BRDF_HIP_PG_MULTI (default kMaxCand)

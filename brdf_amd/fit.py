@@ -129,6 +129,35 @@ def cosines(vertices, faces, face_normals, leds, view_origin, *, surfels=None, r
     return out
 
 
+def fit_capture(model: int, images, pixel_map, vertices, faces, face_normals, leds, view_origin, *, rv_mode: int = 0,
+                p0=(0.5, 1.0, 1.0), lb=(0.0, 0.0, 0.0), ub=(100.0, 100.0, 100.0), itmax: int = 100, opts=None, brdf_surfaces=None):
+    """The pixel loop of CBRDFdata::CalcBRDFEquation (brdfdata.cpp:1188-1227) on the device.  images: CUDA uint8
+    [L,H,W,3] (BGR), pixel_map: CUDA int32 [H,W] (face index or -1), mesh as in cosines().  Returns (brdf_surfaces
+    CUDA float64 [nf,3,3] = {kd,ks,n} per face and channel, avg[3], number of pixels that carried a face)."""
+    import torch
+    images, pixel_map = images.contiguous(), pixel_map.contiguous()
+    vertices, faces, face_normals = vertices.contiguous(), faces.contiguous(), face_normals.contiguous()
+    assert images.dtype == torch.uint8 and pixel_map.dtype == torch.int32 and faces.dtype == torch.int32
+    L, H, W = int(images.shape[0]), int(images.shape[1]), int(images.shape[2])
+    nf = int(faces.shape[0])
+    if brdf_surfaces is None:
+        brdf_surfaces = torch.zeros((nf, 3, 3), dtype=torch.float64, device=images.device)
+    la = np.ascontiguousarray(leds, dtype=np.float64).reshape(-1, 3)
+    assert la.shape[0] == L
+    va, pa, lba, uba = _f64(view_origin, 3), _f64(p0, 3), _f64(lb, 3), _f64(ub, 3)
+    oa = _f64(opts, 5) if opts is not None else None
+    avg = np.zeros(3)
+    npx = C.c_longlong(0)
+    with torch.cuda.device(images.device):
+        rc = lib.brdf_hip_fit_capture_dev(model, images.data_ptr(), L, H, W, pixel_map.data_ptr(), vertices.data_ptr(),
+                                          faces.data_ptr(), face_normals.data_ptr(), nf, _dptr(la), _dptr(va), rv_mode,
+                                          _dptr(pa), _dptr(lba), _dptr(uba), itmax, _dptr(oa) if oa is not None else None,
+                                          brdf_surfaces.data_ptr(), _dptr(avg), C.byref(npx), _stream_handle(torch))
+    if rc != 0:
+        raise RuntimeError(f"brdf_hip_fit_capture_dev failed: {last_error()}")
+    return brdf_surfaces, avg, npx.value
+
+
 def host_dlevmar(method: int, model: int, angles: np.ndarray, x: np.ndarray, p0, *, lb=None, ub=None, dscl=None,
                  itmax=100, opts=None, want_covar=False) -> FitResult:
     """The drop-in call exactly as brdfdata.cpp:1058/1119 makes it: HOST arrays, a BRDFFunc-style callback

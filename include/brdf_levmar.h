@@ -144,6 +144,24 @@ int brdf_hip_cosines_dev(const double *d_vertices, const int *d_faces, const dou
 /* CBRDFdata::InitLEDs (brdfdata.cpp:683-752): the capture rig's 16 LED positions, row-major [16][3] (host) */
 void brdf_hip_led_table(double *leds16x3);
 
+/* ---- the capture loop ---------------------------------------------------------- */
+/* Replaces the pixel loop of CBRDFdata::CalcBRDFEquation (brdfdata.cpp:1188-1227) with its callees
+ * GetIntensities_FromPixel (:945-960), GetCos* (:799-943), SolveEquation (:1077-1136: dlevmar_bc_dif, n = L) and
+ * SaveValuesToSurface (:368-377).  For every pixel (x outer, y inner, as the reference walks) whose pixel-map entry is a
+ * face index: the L intensities image_i(H-1-y, x)[channel] / 255.0 of each of the three channels (B, G, R) are fitted
+ * from p0 and the result is stored in d_brdf_surfaces[face][channel] = {kd, ks, n}; when several pixels carry the same
+ * face the LAST one in the reference's walk wins, as in the reference.  Faces no pixel carries are left untouched.
+ *   d_images[L][H][W][3]: the L captures, 8-bit BGR, row-major (cv::Mat CV_8UC3); d_pixel_map[H][W]: face index or -1
+ *   (pixelMap.at<int>(y, x)); mesh, leds, view_origin, rv_mode: as brdf_hip_cosines_dev; p0/lb/ub/opts: HOST.
+ *   avg (host, or NULL): sum over all fits of kd, ks, n divided by (nf * 3), the statistics of brdfdata.cpp:1224-1226;
+ *   n_pixels (host, or NULL): number of pixels that carried a face (3 fits each).
+ * Synchronises `stream` before returning.  Returns 0, or LM_ERROR with a message in brdf_hip_last_error(). */
+int brdf_hip_fit_capture_dev(int model, const unsigned char *d_images, int L, int H, int W, const int *d_pixel_map,
+                             const double *d_vertices, const int *d_faces, const double *d_face_normals, int nf,
+                             const double *leds, const double *view_origin, int rv_mode, const double *p0, const double *lb,
+                             const double *ub, int itmax, const double *opts, double *d_brdf_surfaces, double *avg,
+                             long long *n_pixels, void *stream);
+
 /* ---- diagnostics ----------------------------------------------------------------------------------- */
 int brdf_hip_device_count(void);
 const char *brdf_hip_last_error(void);

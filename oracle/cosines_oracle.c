@@ -81,3 +81,37 @@ void orc_led_table(double *out) { /* brdfdata.cpp:695-752, written out entry by 
     out[3 * i + 2] = yz[i][1];
   }
 }
+
+/* The pixel loop of CBRDFdata::CalcBRDFEquation (brdfdata.cpp:1188-1227) with GetIntensities_FromPixel (:945-960),
+ * SolveEquation (:1077-1136) and SaveValuesToSurface (:368-377), restated on plain arrays.  PARITY UNPINNED (OpenCV /
+ * Eigen types, no fixtures); the reference's slips in SolveEquation's plane packing (:1102) are not reproduced: the
+ * fit reads the three planes orc_cosines produces.  images[L][H][W][3] (8-bit BGR), pixel_map[H][W].
+ * brdf_surfaces[nf][3][3]; avg[3]; returns the number of pixels that carried a face. */
+#include "oracle.h"
+
+long long orc_fit_capture(int model, const unsigned char *images, int L, int H, int W, const int *pixel_map,
+                          const double *vertices, const int *faces, const double *normals, int nf, const double *leds,
+                          const double *view, int rv_mode, const double *p0, const double *lb, const double *ub, int itmax,
+                          const double *opts, double *brdf_surfaces, double *avg) {
+  long long count = 0;
+  double sum[3] = {0.0, 0.0, 0.0};
+  double angles[3 * 64], I[64];
+  for (int x = 0; x < W; ++x)
+    for (int y = 0; y < H; ++y) {
+      const int f = pixel_map[(size_t)y * W + x];
+      if (!(f > -1) || f >= nf) continue;
+      ++count;
+      orc_cosines(vertices, faces, normals, &f, 1, leds, L, view, rv_mode, angles);
+      for (int c = 0; c < 3; ++c) {
+        for (int i = 0; i < L; ++i) I[i] = images[(((size_t)i * H + (size_t)(H - 1 - y)) * W + x) * 3 + c] / 255.0;
+        double p[3] = {p0[0], p0[1], p0[2]}, info[10];
+        (void)orc_brdf_fit(1, model, angles, I, L, p, itmax, (double *)opts, (double *)lb, (double *)ub, info);
+        for (int k = 0; k < 3; ++k) {
+          brdf_surfaces[((size_t)f * 3 + c) * 3 + k] = p[k];
+          sum[k] += p[k];
+        }
+      }
+    }
+  for (int k = 0; k < 3; ++k) avg[k] = sum[k] / ((double)nf * 3);
+  return count;
+}

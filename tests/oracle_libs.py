@@ -85,3 +85,21 @@ def led_table():
     out = np.zeros(48)
     orc.orc_led_table(ptr(out))
     return out.reshape(16, 3)
+
+
+def fit_capture(model, images, pixel_map, vertices, faces, normals, leds, view, rv_mode=0, p0=(0.5, 1.0, 1.0),
+                lb=(0.0, 0.0, 0.0), ub=(100.0, 100.0, 100.0), itmax=100, opts=None):
+    """oracle/cosines_oracle.c: orc_fit_capture -> (brdf_surfaces[nf,3,3], avg[3], pixels)"""
+    img = np.ascontiguousarray(images, dtype=np.uint8)
+    pm = np.ascontiguousarray(pixel_map, dtype=np.int32)
+    Lc, H, W = img.shape[:3]
+    fc = np.ascontiguousarray(np.asarray(faces, dtype=np.int32).reshape(-1))
+    nf = fc.size // 3
+    out = np.zeros((nf, 3, 3))
+    avg = np.zeros(3)
+    IP = C.POINTER(C.c_int)
+    orc.orc_fit_capture.restype = C.c_longlong
+    n = orc.orc_fit_capture(model, img.ctypes.data_as(C.c_void_p), Lc, H, W, pm.ctypes.data_as(IP), ptr(f64(vertices)),
+                            fc.ctypes.data_as(IP), ptr(f64(normals)), nf, ptr(f64(leds)), ptr(f64(view)), rv_mode, ptr(f64(p0)),
+                            ptr(f64(lb)), ptr(f64(ub)), itmax, ptr(f64(opts)), ptr(out), ptr(avg))
+    return out, avg, n

@@ -131,3 +131,83 @@ def test_cosines_feed_the_batched_fitter(gpu):
         assert ret[s] >= 0 or r < 0
         if r >= 0 and ret[s] >= 0:
             assert info[s, 1] <= info_ref[1] * (1 + 1e-3) + 1e-20
+
+
+# ---- the capture loop (brdfdata.cpp:1188-1227) ------------------------------------
+def make_capture(H=23, W=31, nf=40, seed=5):
+    """a synthetic capture: a lit mesh, a pixel map with holes and with several pixels per face, and 16 8-bit BGR images
+    rendered from per-face, per-channel Blinn-Phong truths through the cosines of the oracle"""
+    from brdf_amd import synth
+    vertices, faces, nrm, view = make_mesh(nv=200, nf=nf, seed=seed)
+    leds = L.led_table()
+    c = vertices[faces].sum(axis=1) / 3.0
+    flip = ((leds.mean(axis=0)[None, :] - c) * nrm).sum(axis=1) < 0
+    nrm[flip] *= -1.0
+    rng = np.random.default_rng(seed)
+    pixel_map = rng.integers(-1, nf - 3, size=(H, W)).astype(np.int32)  # -1 = background; the last faces get no pixel
+    pixel_map[rng.random((H, W)) < 0.3] = -1
+    ang = np.abs(L.cosines(vertices, faces, nrm, leds, view, rv_mode=1))  # [nf,3,16]
+    images = np.zeros((16, H, W, 3), dtype=np.uint8)
+    truth = np.array(synth.TRUTH[1])
+    for y in range(H):
+        for x in range(W):
+            f = pixel_map[y, x]
+            if f < 0:
+                continue
+            for ch in range(3):
+                val = L.model_values(1, ang[f], truth * (0.6 + 0.2 * ch))
+                images[:, H - 1 - y, x, ch] = np.clip(np.round(val * 255.0 * 0.5), 0, 255).astype(np.uint8)
+    return vertices, faces, nrm, view, leds, pixel_map, images
+
+
+def _objective(model, angles, x, p):
+    e = x - L.model_values(model, angles, p)
+    return float(e @ e)
+
+
+def test_capture_oracle_walks_like_the_reference():
+    """x outer / y inner, image row H-1-y, value/255, three channels per pixel, last pixel of a face wins"""
+    vertices, faces, nrm, view, leds, pixel_map, images = make_capture()
+    surf, avg, npx = L.fit_capture(1, images, pixel_map, vertices, faces, nrm, leds, view, rv_mode=1, opts=(1e-3, 1e-15, 1e-15, 1e-20, 1e-6))
+    assert npx == int((pixel_map > -1).sum())
+    untouched = np.setdiff1d(np.arange(faces.shape[0]), np.unique(pixel_map[pixel_map > -1]))
+    assert untouched.size > 0 and np.all(surf[untouched] == 0.0)
+    ang = np.abs(L.cosines(vertices, faces, nrm, leds, view, rv_mode=1))
+    H, W = pixel_map.shape
+    f = int(pixel_map[pixel_map > -1][0])
+    last = max((x, y) for y in range(H) for x in range(W) if pixel_map[y, x] == f)  # x-major order: the largest (x, y)
+    x_, y_ = last
+    for ch in range(3):
+        I = images[:, H - 1 - y_, x_, ch] / 255.0
+        _, p_ref, _ = L.brdf_fit("orc", 1, 1, L.cosines(vertices, faces, nrm, leds, view, surfels=[f], rv_mode=1)[0], I, (0.5, 1.0, 1.0),
+                                 100, (1e-3, 1e-15, 1e-15, 1e-20, 1e-6), (0.0, 0.0, 0.0), (100.0, 100.0, 100.0))
+        assert np.array_equal(surf[f, ch], p_ref)
+    assert np.all(np.isfinite(avg))
+
+
+@pytest.mark.gpu
+def test_device_capture_loop_against_oracle(gpu):
+    torch, brdf_amd, dev = gpu
+    vertices, faces, nrm, view, leds, pixel_map, images = make_capture()
+    opts = (1e-3, 1e-15, 1e-15, 1e-20, 1e-6)
+    want, avg_ref, npx_ref = L.fit_capture(1, images, pixel_map, vertices, faces, nrm, leds, view, rv_mode=1, opts=opts)
+    tv, tf, tn = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (vertices, faces, nrm))
+    got, avg, npx = brdf_amd.fit_capture(1, torch.from_numpy(images).to(dev), torch.from_numpy(pixel_map).to(dev), tv, tf, tn, leds, view,
+                                         rv_mode=1, opts=opts)
+    got = got.cpu().numpy()
+    assert npx == npx_ref
+    touched = np.unique(pixel_map[pixel_map > -1])
+    untouched = np.setdiff1d(np.arange(faces.shape[0]), touched)
+    assert np.all(got[untouched] == 0.0)
+    # 16-sample fits are ill-conditioned (SURVEY.md section 6 ii): parity on the objective of the pixel that owns the face
+    ang = L.cosines(vertices, faces, nrm, leds, view, rv_mode=1)
+    H, W = pixel_map.shape
+    worst = 0.0
+    for f in touched:
+        x_, y_ = max((x, y) for y in range(H) for x in range(W) if pixel_map[y, x] == f)
+        for ch in range(3):
+            I = images[:, H - 1 - y_, x_, ch] / 255.0
+            o_got, o_ref = _objective(1, ang[f], I, got[f, ch]), _objective(1, ang[f], I, want[f, ch])
+            assert o_got <= o_ref * (1 + 1e-3) + 1e-12, (f, ch, got[f, ch], want[f, ch])
+            worst = max(worst, L.rel_err(got[f, ch], want[f, ch]))
+    assert np.all(np.isfinite(avg)) and np.all(np.abs(avg - avg_ref) <= 0.05 * np.abs(avg_ref) + 1e-6)
