@@ -1,32 +1,35 @@
 // resident_fit.hip -- "resident" regime: ONE launch per fit, the samples never leave the chip.
 //
 // For fits that fit the chip's register file + LDS (n <= #CUs * 4096 samples, i.e. 1,048,576 on MI355X) the whole
-// fit runs inside one launch of #CUs workgroups (one per CU, all co-resident).  Every workgroup reads its tile of
-// the sample planes from HBM exactly once and keeps it for the rest of the fit:
+// fit runs inside one launch of #CUs workgroups (one 512-thread workgroup per CU, all co-resident).  Every workgroup
+// reads its tile of the sample planes from HBM exactly once and keeps it for the rest of the fit:
 //
-//   registers (per lane, 8 samples)   c0, x, the two per-sample invariants (brdf_models.h: Prep) and, for
-//                                     dlevmar_dif, f(p) and f(p+Dp)                      (lm_core.c:551, :742)
-//   LDS (dlevmar_dif only, 128 KiB)   the secant Jacobian rows (3 planes) and the pending Broyden coefficient
-//                                                                                         (lm_core.c:759-769)
+//   waves 1..7, "sample waves"         per lane 10 samples in registers: c0, x, the two per-sample invariants
+//                                      (brdf_models.h: Prep) and, for dlevmar_dif, f(p) and f(p+Dp) (lm_core.c:551, :742)
+//   LDS (dlevmar_dif only, 105 KiB)    the secant Jacobian rows, three SoA planes            (lm_core.c:759-769)
+//   wave 0, "control wave"             no samples: it runs the exchange and the serial LM step, so the step's ~150
+//                                      live registers never compete with the resident samples (a symmetric
+//                                      eight-wave version spilled 40-120 VGPRs and lost to the launch chain)
 //
 // A pass (= one LM evaluation: e=x-hx / ||e||^2, FD Jacobian, J^T J / J^T e, Broyden update, brdfdata.cpp:975-988 +
 // misc_core.c:153-171 + lm_core.c:617-653) therefore moves no sample bytes at all.  Passes are separated by an
-// in-launch ALL-GATHER of the per-workgroup partial sums instead of a kernel boundary:
+// in-launch exchange of the per-workgroup partial sums instead of a kernel boundary:
 //
-//   every workgroup : sweep -> workgroup reduction -> its <=14 partial sums as tagged 8-byte granules
-//                     {epoch tag : 32, half of the double : 32}, each ONE write-through (sc1) store
-//   every workgroup : thread r re-reads row r's granules (L1-bypassing loads) until every tag equals the epoch,
-//                     then all rows are folded in a fixed order and the workgroup steps ITS OWN copy of the LM
-//                     state machine (lm_machine.h) -- the same redundant execution as the launch chain of
-//                     stream_fit.hip, so there is no second hop (no ticket, no "last arriver", no broadcast)
+//   sample waves : sweep -> reduction over the seven waves -> <= 14 partial sums in LDS            (barriers X1, X2)
+//   control wave : publishes them as tagged 8-byte granules {tag : 32, half of a double : 32}, each ONE write-through
+//                  (sc1) store; gathers everybody's in two levels (control_exchange below); folds in a fixed order;
+//                  steps ITS OWN copy of the LM state machine (lm_machine.h) -- the same redundant execution as in
+//                  the launch chain of stream_fit.hip, so there is no broadcast hop; builds the next pass's uniforms
+//                                                                                                       (barrier B)
 //
-// This is recipe R2 of the CDNA guide (cdna_hip_programming.md, Guideline 16: "the data IS the flag"): a granule is
-// one naturally aligned 8-byte word written by one store, so it cannot tear; no flag, no fence, no ordering between
-// granules is needed.  The rows are double-buffered by epoch parity: a workgroup can be at most one epoch ahead of
-// the slowest one (it needs everybody's row of epoch e+1 before it can publish epoch e+2), so two buffers suffice.
-// Results do not depend on dispatch order or XCD placement (fold order = workgroup index).  Every spin is bounded by
-// a wall-clock budget: if the grid is not co-resident (or anything else goes wrong) all workgroups drain, the launch
-// ends with ctl->abort set and the host falls back to the launch chain.
+// The granules are recipe R2 of the CDNA guide (cdna_hip_programming.md, Guideline 16: "the data IS the flag"): a
+// granule is one naturally aligned 8-byte word written by one store, so it cannot tear; no flag, no fence, no ordering
+// between granules is needed.  Tags are (launch base + epoch + 1): the tables are never zeroed between fits.  They
+// are double-buffered by epoch parity: a workgroup can be at most one epoch ahead of the slowest one (it needs
+// everybody's row of epoch e+1 before it can publish epoch e+2), so two buffers suffice.  Results do not depend on
+// dispatch order or XCD placement (fold order = workgroup index).  Every spin is bounded by a wall-clock budget: if
+// the grid is not co-resident (or anything else goes wrong) all workgroups drain, the launch ends with ctl->abort set
+// and the host falls back to the launch chain (tests/test_gpu_parity.py exercises that path by sabotage).
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -46,7 +49,7 @@ constexpr int kRCap = kRWorkers * kRSpt;      // sample slots per workgroup
 constexpr int kRowWords = 2 * kSlots;         // 8-byte granules per partial row: 2 per slot
 constexpr int kRowStride = 256;               // workgroups per granule word (>= #CUs), a whole number of lines
 constexpr int kRedCols = kRWorkers / 4;       // reduction buffer columns (after two in-row DPP steps)
-constexpr long long kSpinBudgetTicks = 200000000LL;  // 2 s of s_memrealtime (100 MHz) per wait
+constexpr long long kSpinBudgetTicks = 200000000LL;  // default budget per wait: 2 s of s_memrealtime (100 MHz)
 
 typedef unsigned long long u64;
 
@@ -65,6 +68,8 @@ struct ResidentCtx {
   Mailbox *mbox;
   int n;
   unsigned tag_base;  // tags of this launch are tag_base + epoch + 1: the rows need no zeroing between launches
+  long long spin_ticks;  // budget of one wait (s_memrealtime ticks)
+  int sabotage_epoch;    // test hook (BRDF_HIP_RESIDENT_SABOTAGE): the last workgroup withholds its row at this epoch; -1 = never
 };
 
 template <int METHOD>
@@ -197,7 +202,7 @@ __device__ __forceinline__ bool gather_row(const ResidentCtx &ctx, const u64 *g,
       }
       if ((spins & 63u) == 63u) {
         if (__hip_atomic_load(&ctx.ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
-            (long long)wall_clock64() - t0 > kSpinBudgetTicks) {
+            (long long)wall_clock64() - t0 > ctx.spin_ticks) {
           __hip_atomic_store(&ctx.ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           failed = true;
           break;
@@ -221,9 +226,10 @@ __device__ __forceinline__ bool control_exchange(const ResidentCtx &ctx, unsigne
   const unsigned tag = ctx.tag_base + epoch + 1u;
   u64 *rows = ctx.rows + (size_t)(epoch & 1u) * kRowWords * kRowStride;
   u64 *groups = ctx.groups + (size_t)(epoch & 1u) * kRowWords * kGroupStride;
-  if (lane < NS)
+  const bool withhold = (int)epoch == ctx.sabotage_epoch && blockIdx.x == gridDim.x - 1;  // test hook, see ResidentCtx
+  if (lane < NS && !withhold)
     put_value(rows, kRowStride, 2 * lane, blockIdx.x, tag, sums[lane]);
-  else if (lane == kSums)
+  else if (lane == kSums && !withhold)
     put_value(rows, kRowStride, 2 * kSums, blockIdx.x, tag, sums[kSums]);
 
   double pv[NS], pmx;
@@ -620,6 +626,10 @@ int resident_attempt(const StreamFitArgs &a, RWorkspace &ws, bool *retry_exact, 
   c.mbox = ws.d_mbox;
   c.n = a.n;
   c.tag_base = ws.tag_base;
+  c.spin_ticks = kSpinBudgetTicks;
+  c.sabotage_epoch = -1;
+  if (const char *e = getenv("BRDF_HIP_RESIDENT_SPIN_MS")) c.spin_ticks = std::max(1LL, atoll(e)) * 100000LL;
+  if (const char *e = getenv("BRDF_HIP_RESIDENT_SABOTAGE")) c.sabotage_epoch = atoi(e);  // tests only: forces the fallback
 
   hipLaunchKernelGGL((resident_fit_kernel<MODEL, METHOD, FAST>), dim3(G), dim3(kRThreads), 0, a.stream, c);
   HIP_OK(hipGetLastError());

@@ -318,6 +318,25 @@ def test_resident_and_launch_chain_regimes(gpu, monkeypatch):
                 assert (st["launches"] == 1) == (env == "1"), st
 
 
+def test_resident_regime_falls_back_when_a_workgroup_never_arrives(gpu, monkeypatch, capfd):
+    """every spin of the resident kernel is bounded: with one workgroup withholding its partial row (test hook) the
+    launch drains, reports `abort`, and the host redoes the fit with the launch chain -- same answer, no hang"""
+    torch, brdf_amd, dev = gpu
+    monkeypatch.setenv("BRDF_HIP_RESIDENT", "1")
+    monkeypatch.setenv("BRDF_HIP_RESIDENT_SABOTAGE", "3")
+    monkeypatch.setenv("BRDF_HIP_RESIDENT_SPIN_MS", "20")
+    model, n = 2, 100000
+    angles, x, _ = synth.make_single(model, n)
+    for method in (0, 1):
+        _, p_ref, info_ref = L.brdf_fit("orc", method, model, angles, x, synth.P0[model], synth.ITMAX, synth.OPTS, synth.LB, synth.UB)
+        _check(_dev_fit(gpu, method, model, angles, x), p_ref, info_ref)
+        assert brdf_amd.last_fit_stats()["launches"] > 1  # the launch chain did the work
+    monkeypatch.delenv("BRDF_HIP_RESIDENT_SABOTAGE")
+    _check(_dev_fit(gpu, 0, model, angles, x), *L.brdf_fit("orc", 0, model, angles, x, synth.P0[model], synth.ITMAX, synth.OPTS,
+                                                          synth.LB, synth.UB)[1:])
+    assert brdf_amd.last_fit_stats()["launches"] == 1  # and the resident regime works again afterwards (tags restarted)
+
+
 def test_diagonal_scaling_and_nan_input(gpu):
     """dscl (lmbc_core.c:536-540, :555-569) and the stop-reason-7 path (non-finite function values ->
     LM_ERROR, lm_core.c:562, :749; lmbc_core.c:534)"""
