@@ -33,6 +33,8 @@ ABI = {
     "brdf_hip_register_model": (C.c_int, [C.c_void_p]),
     "brdf_hip_unregister_model": (C.c_int, [C.c_void_p]),
     "BRDFFunc_hip": (None, [D, D, C.c_int, C.c_int, C.c_void_p]),
+    "BRDFJac_hip": (None, [D, D, C.c_int, C.c_int, C.c_void_p]),
+    "dlevmar_chkjac": (None, [C.c_void_p, C.c_void_p, D, C.c_int, C.c_int, C.c_void_p, D]),
     "brdf_hip_fit_dev": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, D, D, D, D, C.c_int, D, D, D,
                                    C.c_void_p]),
     "brdf_hip_fit_batch_dev": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, D, D,

@@ -68,6 +68,19 @@ struct BrdfModel<MODEL_PHONG> {
   template <bool FAST>
   static LM_HD double shape(const Nl &u, double, const Prep &q) { return FAST ? exp(u.u0 * q.q1) : pow(q.q1, u.u0); }
   static LM_HD double combine(const Lin &l, double c0, double s) { return l.a * c0 + l.b * s; }
+  // analytic Jacobian row (not in the reference): with A = (p2+2)/2*PI, s = pow(c2, p2):
+  //   df/dp0 = c0,  df/dp1 = A s,  df/dp2 = (1/2*PI p1) s + ((A p1) s) log c2
+  static LM_HD void an_scalars(const double *p, double *an) {
+    an[0] = (p[2] + 2.0) / 2.0 * kPi;
+    an[1] = (1.0 / 2.0 * kPi) * p[1];
+  }
+  template <bool FAST>
+  static LM_HD void an_row(const double *an, const Lin &l, const Nl &, double c0, const Prep &q, double s, double *j) {
+    const double lc = FAST ? q.q1 : log(q.q1);
+    j[0] = c0;
+    j[1] = an[0] * s;
+    j[2] = an[1] * s + (l.b * s) * lc;
+  }
 };
 
 // Blinn-Phong: x = p0*c0 + p1*pow(c1,p2)                    brdfdata.cpp:986
@@ -83,6 +96,18 @@ struct BrdfModel<MODEL_BLINN_PHONG> {
   template <bool FAST>
   static LM_HD double shape(const Nl &u, double, const Prep &q) { return FAST ? exp(u.u0 * q.q1) : pow(q.q1, u.u0); }
   static LM_HD double combine(const Lin &l, double c0, double s) { return l.a * c0 + l.b * s; }
+  // analytic Jacobian row: s = pow(c1, p2):  df/dp0 = c0,  df/dp1 = s,  df/dp2 = (p1 s) log c1
+  static LM_HD void an_scalars(const double *p, double *an) {
+    an[0] = p[1];
+    an[1] = 0.0;
+  }
+  template <bool FAST>
+  static LM_HD void an_row(const double *an, const Lin &, const Nl &, double c0, const Prep &q, double s, double *j) {
+    const double lc = FAST ? q.q1 : log(q.q1);
+    j[0] = c0;
+    j[1] = s;
+    j[2] = (an[0] * s) * lc;
+  }
 };
 
 // Ward (isotropic, build-defined): with a2 = p2^2, t2 = tan^2(theta_h), rinv = 1/sqrt(c0 c2)
@@ -111,6 +136,19 @@ struct BrdfModel<MODEL_WARD> {
     return (u.u1 * g) * v.q2;
   }
   static LM_HD double combine(const Lin &l, double c0, double s) { return c0 * (l.a + l.b * s); }
+  // analytic Jacobian row: with S = (k g) rinv (what shape() returns), k = 1/(4 PI a2), g = exp(-t2/a2), a2 = p2^2:
+  //   df/dp0 = c0/PI,  df/dp1 = c0 S,  df/dp2 = c0 ((p1 S) ((2/p2) (t2/a2 - 1)))        (dk/dp2 = -2k/p2, dg/dp2 = g t2 2/p2^3)
+  static LM_HD void an_scalars(const double *p, double *an) {
+    an[0] = p[1];
+    an[1] = 2.0 / p[2];
+  }
+  template <bool FAST>
+  static LM_HD void an_row(const double *an, const Lin &, const Nl &u, double c0, const Prep &q, double s, double *j) {
+    const double t2 = FAST ? q.q1 : ward_invariants(c0, q.q1, q.q2).q1;
+    j[0] = c0 / kPi;
+    j[1] = c0 * s;
+    j[2] = c0 * ((an[0] * s) * (an[1] * (t2 * u.u0 - 1.0)));
+  }
 };
 
 // ---- per-pass uniforms derived from a Request<3> ---------------------------------------------------
@@ -130,13 +168,15 @@ struct PassUniforms {
   Lin lk[kMaxCand];  // at the candidate points     (RQ_EVAL_MULTI)
   Nl nk[kMaxCand];
   double dp[kM], dp_l2, scal;
-  int central, ncand;
+  double an[2];      // scalars of the analytic Jacobian (Mdl::an_scalars), RQ_JAC with analytic = 1
+  int central, ncand, analytic;
 
   // only what the request kind reads is computed (each lin()/nl() hides an fp64 division or two, and on the
   // device this runs on a single lane between two passes)
   // need_base = false: the caller keeps f(p) per sample (resident regime), so a dif trial pass evaluates f at q only
-  LM_HD void build(const Request<kM> &r, bool need_base = true) {
+  LM_HD void build(const Request<kM> &r, bool need_base = true, bool analytic_jac = false) {
     ncand = 0;
+    analytic = analytic_jac ? 1 : 0;
     if (r.kind == RQ_EVAL_MULTI) {
       ncand = r.nk;
       for (int j = 0; j < kMaxCand; ++j)
@@ -154,7 +194,9 @@ struct PassUniforms {
     scal = r.scal;
     dp_l2 = r.dp_l2;
     for (int j = 0; j < kM; ++j) dp[j] = r.dp[j];
-    if (r.kind == RQ_JAC || r.kind == RQ_DIF_JAC) {
+    if (r.kind == RQ_JAC && analytic_jac) {
+      Mdl::an_scalars(r.p, an);
+    } else if (r.kind == RQ_JAC || r.kind == RQ_DIF_JAC) {
       for (int j = 0; j < kM; ++j) {
         double pp[kM] = {r.p[0], r.p[1], r.p[2]};
         pp[j] = r.p[j] + r.d[j];  // "p[j]+=d", misc_core.c:161 / "tmp+d", :202
@@ -215,6 +257,15 @@ LM_HD void model_fd_row(const PassUniforms<MODEL> &u, double c0, const Prep &q, 
     jrow[1] = (Mdl::combine(u.lp[1], c0, s0) - Mdl::combine(u.lm[1], c0, s0)) * u.dinv[1];
     jrow[2] = (Mdl::combine(u.lp[2], c0, sp) - Mdl::combine(u.lm[2], c0, sm)) * u.dinv[2];
   }
+}
+
+// f(p) and one row of the analytic Jacobian (the caller's jacf of dlevmar_bc_der, lmbc_core.c:578, for a built-in model)
+template <int MODEL, bool FAST>
+LM_HD void model_an_row(const PassUniforms<MODEL> &u, double c0, const Prep &q, double &f0, double *jrow) {
+  using Mdl = BrdfModel<MODEL>;
+  const double s = Mdl::template shape<FAST>(u.n0, c0, q);
+  f0 = Mdl::combine(u.l0, c0, s);
+  Mdl::template an_row<FAST>(u.an, u.l0, u.n0, c0, q, s, jrow);
 }
 
 // Broyden rank-one update of one Jacobian row, lm_core.c:760-766

@@ -8,6 +8,9 @@
 #include <cstring>
 #include <mutex>
 
+#include <cfloat>
+#include <vector>
+
 #include "../../include/brdf_levmar.h"
 #include "batch_fit.h"
 #include "stream_fit.h"
@@ -17,6 +20,8 @@ int generic_fit_run(int method, void (*func)(double *, double *, int, int, void 
                     void (*jacf)(double *, double *, int, int, void *), double *p, double *x, int m, int n, double *lb,
                     double *ub, double *dscl, int itmax, double *opts, double *info, double *covar, void *adata);
 int model_eval_run(int model, const double *d_angles, int n, const double *p, double *d_hx, hipStream_t stream);
+int model_jac_run(int model, const double *d_angles, int n, const double *p, double *d_jac, hipStream_t stream);
+int chkjac_err_run(const double *fvec, const double *fjac, const double *fvecp, const double *p, int m, int n, double *err);
 }
 
 using namespace brdf;
@@ -54,7 +59,7 @@ struct DevBuf {
 };
 
 int host_fit(int method, const char *who, model_func_t func, double *p, double *x, int m, int n, double *lb,
-             double *ub, double *dscl, int itmax, double *opts, double *info, double *covar, void *adata) {
+             double *ub, double *dscl, int itmax, double *opts, double *info, double *covar, void *adata, int analytic = 0) {
   if (!func) {
     set_error("%s(): func is NULL", who);
     return LM_ERROR;
@@ -101,6 +106,7 @@ int host_fit(int method, const char *who, model_func_t func, double *p, double *
   }
   StreamFitArgs a;
   a.method = method;
+  a.analytic = analytic;
   a.model = ed->modelInfo;
   a.d_angles = angles.ptr;
   a.d_x = xs.ptr;
@@ -163,6 +169,9 @@ int dlevmar_bc_der(void (*func)(double *, double *, int, int, void *), void (*ja
               "use dlevmar_bc_dif() rather than dlevmar_bc_der()");
     return LM_ERROR;
   }
+  if (is_registered(func) && jacf == &BRDFJac_hip)  // a built-in model with its own analytic Jacobian: all on the device
+    return host_fit(BRDF_METHOD_BC_DIF, "dlevmar_bc_der", func, p, x, m, n, lb, ub, dscl, itmax, opts, info, covar, adata,
+                    /*analytic=*/1);
   return generic_fit_run(BRDF_METHOD_BC_DIF, func, jacf, p, x, m, n, lb, ub, dscl, itmax, opts, info, covar, adata);
 }
 
@@ -217,11 +226,55 @@ void BRDFFunc_hip(double *p, double *hx, int m, int n, void *adata) {
   if (e != hipSuccess) set_error("BRDFFunc_hip(): device->host copy failed: %s", hipGetErrorString(e));
 }
 
+void BRDFJac_hip(double *p, double *jac, int m, int n, void *adata) {
+  const brdf_extra_data *ed = static_cast<const brdf_extra_data *>(adata);
+  if (!p || !jac || !ed || !ed->angles || m != kM || n <= 0) {
+    set_error("BRDFJac_hip(): bad arguments");
+    return;
+  }
+  if (ed->modelInfo < 0 || ed->modelInfo >= MODEL_COUNT) return;
+  DevBuf angles, out;
+  if (angles.alloc(3 * (size_t)n) || out.alloc(3 * (size_t)n)) return;
+  const bool need1 = ed->modelInfo != MODEL_PHONG, need2 = ed->modelInfo != MODEL_BLINN_PHONG;
+  hipError_t e = hipMemcpy(angles.ptr, ed->angles, sizeof(double) * n, hipMemcpyHostToDevice);
+  if (e == hipSuccess && need1) e = hipMemcpy(angles.ptr + n, ed->angles + n, sizeof(double) * n, hipMemcpyHostToDevice);
+  if (e == hipSuccess && need2)
+    e = hipMemcpy(angles.ptr + 2 * (size_t)n, ed->angles + 2 * (size_t)n, sizeof(double) * n, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    set_error("BRDFJac_hip(): host->device copy failed: %s", hipGetErrorString(e));
+    return;
+  }
+  if (model_jac_run(ed->modelInfo, angles.ptr, n, p, out.ptr, nullptr) != 0) return;
+  e = hipMemcpy(jac, out.ptr, sizeof(double) * 3 * n, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) set_error("BRDFJac_hip(): device->host copy failed: %s", hipGetErrorString(e));
+}
+
+void dlevmar_chkjac(void (*func)(double *, double *, int, int, void *), void (*jacf)(double *, double *, int, int, void *),
+                    double *p, int m, int n, void *adata, double *err) {
+  if (!func || !jacf || !p || !err || m <= 0 || n <= 0) {
+    set_error("dlevmar_chkjac(): bad arguments");
+    return;
+  }
+  // misc_core.c:268-301: f(p), J(p), f(p + eps |p|) through the caller's callbacks; the n-sized comparison on the device
+  std::vector<double> fvec(n), fjac((size_t)n * m), pp(m), fvecp(n);
+  const double eps = sqrt(DBL_EPSILON);
+  (*func)(p, fvec.data(), m, n, adata);
+  (*jacf)(p, fjac.data(), m, n, adata);
+  for (int j = 0; j < m; ++j) {
+    double temp = eps * fabs(p[j]);
+    if (temp == 0.0) temp = eps;
+    pp[j] = p[j] + temp;
+  }
+  (*func)(pp.data(), fvecp.data(), m, n, adata);
+  (void)chkjac_err_run(fvec.data(), fjac.data(), fvecp.data(), p, m, n, err);
+}
+
 int brdf_hip_fit_dev(int method, int model, const double *d_angles, const double *d_x, int n, double *p,
                      const double *lb, const double *ub, const double *dscl, int itmax, const double *opts,
                      double *info, double *covar, void *stream) {
   StreamFitArgs a;
-  a.method = method;
+  a.method = (method == BRDF_METHOD_BC_DER) ? BRDF_METHOD_BC_DIF : method;
+  a.analytic = (method == BRDF_METHOD_BC_DER) ? 1 : 0;
   a.model = model;
   a.d_angles = d_angles;
   a.d_x = d_x;

@@ -428,4 +428,56 @@ int generic_fit_run(int method, user_func_t func, user_jacf_t jacf, double *p, d
   return generic_dispatch<1>(func, jacf, p, x, m, n, lb, ub, dscl, itmax, opts, info, covar, adata);
 }
 
+
+// dlevmar_chkjac's comparison of the n rows (misc_core.c:286-318), one row per lane
+__global__ __launch_bounds__(256) void chkjac_kernel(const double *__restrict__ fvec, const double *__restrict__ fjac,
+                                                     const double *__restrict__ fvecp, const double *__restrict__ pabs, int m, int n,
+                                                     double *__restrict__ err) {
+  const double epsmch = DBL_EPSILON, eps = sqrt(epsmch), epsf = 100.0 * epsmch, epslog = log10(eps);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    double e = 0.0;
+    for (int j = 0; j < m; ++j) e += pabs[j] * fjac[(size_t)i * m + j];  // temp = |p[j]| (1 if zero), :290-296
+    double temp = 1.0;
+    const double f = fvec[i], fp = fvecp[i];
+    if (f != 0.0 && fp != 0.0 && fabs(fp - f) >= epsf * fabs(f)) temp = eps * fabs((fp - f) / eps - e) / (fabs(f) + fabs(fp));
+    double r = 1.0;
+    if (temp > epsmch && temp < eps) r = (log10(temp) - epslog) / epslog;
+    if (temp >= eps) r = 0.0;
+    err[i] = r;
+  }
+}
+
+int chkjac_err_run(const double *fvec, const double *fjac, const double *fvecp, const double *p, int m, int n, double *err) {
+  (void)hipGetLastError();
+  double *d = nullptr;
+  const size_t total = (size_t)n * (m + 3) + m;
+  if (hipMalloc(&d, total * sizeof(double)) != hipSuccess) {
+    set_error("dlevmar_chkjac(): hipMalloc failed");
+    return kLmError;
+  }
+  double *d_fvec = d, *d_fvecp = d + n, *d_err = d + 2 * (size_t)n, *d_p = d + 3 * (size_t)n, *d_fjac = d_p + m;
+  std::vector<double> pabs(m);
+  for (int j = 0; j < m; ++j) {
+    pabs[j] = fabs(p[j]);
+    if (pabs[j] == 0.0) pabs[j] = 1.0;
+  }
+  hipError_t e = hipMemcpy(d_fvec, fvec, sizeof(double) * n, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_fvecp, fvecp, sizeof(double) * n, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_fjac, fjac, sizeof(double) * (size_t)n * m, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_p, pabs.data(), sizeof(double) * m, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    int blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(chkjac_kernel, dim3(blocks), dim3(256), 0, nullptr, d_fvec, d_fjac, d_fvecp, d_p, m, n, d_err);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(err, d_err, sizeof(double) * n, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess) {
+    set_error("dlevmar_chkjac(): %s", hipGetErrorString(e));
+    return kLmError;
+  }
+  return 0;
+}
+
 }  // namespace brdf

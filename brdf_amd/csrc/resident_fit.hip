@@ -294,7 +294,12 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
     if (tid <= kM) dp_prev[tid] = 0.0;
   }
   __syncthreads();
-  if (wave == 0) su.build(sm.h.req);
+  if (wave == 0) {
+    if constexpr (METHOD == 1)
+      su.build(sm.h.req, true, sm.c.analytic_jac != 0);
+    else
+      su.build(sm.h.req);
+  }
   __syncthreads();
 
   if (wave == 0) {
@@ -330,7 +335,12 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
         dp_prev[kM] = su.dp_l2;
       }
       sm.template step<true>(sums, sums[kSums]);
-      if (sm.h.req.kind != RQ_DONE) su.build(sm.h.req, /*need_base=*/false);
+      if (sm.h.req.kind != RQ_DONE) {
+        if constexpr (METHOD == 1)
+          su.build(sm.h.req, /*need_base=*/false, sm.c.analytic_jac != 0);
+        else
+          su.build(sm.h.req, /*need_base=*/false);
+      }
       __syncthreads();  // B: the next request and its uniforms are in LDS
       RSTAMP(4);
     }
@@ -460,7 +470,10 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
 #pragma unroll
       for (int k = 0; k < kRSpt; ++k) if (k < nk) {
         double f0 = 0.0, j[kM];
-        model_fd_row<MODEL, FAST>(u, s0[k], pq[k], true, f0, 0.0, false, j);
+        if (u.analytic)  // dlevmar_bc_der with the model's analytic Jacobian
+          model_an_row<MODEL, FAST>(u, s0[k], pq[k], f0, j);
+        else
+          model_fd_row<MODEL, FAST>(u, s0[k], pq[k], true, f0, 0.0, false, j);
         double e = sx[k] - f0;
         if (!(okm >> k & 1u)) e = j[0] = j[1] = j[2] = 0.0;
         acc_normal_eq_fma(j, e, acc, acc + kNL);
@@ -592,6 +605,7 @@ int resident_attempt(const StreamFitArgs &a, RWorkspace &ws, bool *retry_exact, 
     }
   } else {
     m.start(a.p, a.n, a.lb, a.ub, a.dscl, a.itmax, a.opts, a.covar != nullptr, pg_candidates());
+    m.c.analytic_jac = a.analytic ? 1 : 0;
     if (m.h.req.kind == RQ_DONE) {
       switch (m.c.bad_input) {
       case 1: set_error("dlevmar_bc_dif(): cannot solve a problem with fewer measurements [%d] than unknowns [%d]", a.n, kM); break;

@@ -59,6 +59,7 @@ struct StreamCtx {
 // enqueue-and-wait driver; returns the solver's return value (>=0 iterations, or kLmError)
 struct StreamFitArgs {
   int method, model;
+  int analytic = 0;  // method 1 only: dlevmar_bc_der with the model's analytic Jacobian instead of finite differences
   const double *d_angles, *d_x;
   int n;
   double *p;

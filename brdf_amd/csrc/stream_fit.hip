@@ -145,7 +145,12 @@ __global__ __launch_bounds__(kStreamThreads, kStreamWavesPerSimd) void stream_pa
     if (blockIdx.x == 0 && tid == 0) publish_result<METHOD>(ctx, sm, pass);
     return;
   }
-  if (first_wave) su.build(sm.h.req);
+  if (first_wave) {
+    if constexpr (METHOD == 1)
+      su.build(sm.h.req, true, sm.c.analytic_jac != 0);
+    else
+      su.build(sm.h.req);
+  }
   STAMP();
   if (blockIdx.x == 0) {  // persist the advanced machine for the next launch
     const unsigned *src = reinterpret_cast<const unsigned *>(&sm);
@@ -271,7 +276,10 @@ __global__ __launch_bounds__(kStreamThreads, kStreamWavesPerSimd) void stream_pa
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       double f0 = 0.0, j[kM];
-      model_fd_row<MODEL, FAST>(u, s0[k], pq[k], true, f0, 0.0, false, j);
+      if (u.analytic)  // dlevmar_bc_der: the caller's jacf is the model's own analytic Jacobian (lmbc_core.c:578)
+        model_an_row<MODEL, FAST>(u, s0[k], pq[k], f0, j);
+      else
+        model_fd_row<MODEL, FAST>(u, s0[k], pq[k], true, f0, 0.0, false, j);
       double e = sx[k] - f0;
       if (!ok[k]) e = j[0] = j[1] = j[2] = 0.0;
       acc_normal_eq(j, e, acc, acc + kNL);
@@ -377,6 +385,23 @@ __global__ __launch_bounds__(256) void model_eval_kernel(const double *__restric
   u.build(r);
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
     hx[i] = model_value<MODEL, false>(u, c0[i], Mdl::template prepare<false>(c0[i], Mdl::uses_c1 ? c1[i] : 0.0, Mdl::uses_c2 ? c2[i] : 0.0));
+}
+
+// the models' analytic Jacobian alone, n x 3 row-major like every levmar jacf (BRDFJac_hip)
+template <int MODEL>
+__global__ __launch_bounds__(256) void model_jac_kernel(const double *__restrict__ c0, const double *__restrict__ c1,
+                                                        const double *__restrict__ c2, int n, Request<kM> r,
+                                                        double *__restrict__ jac) {
+  using Mdl = BrdfModel<MODEL>;
+  PassUniforms<MODEL> u;
+  u.build(r, true, true);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    double f0, j[kM];
+    model_an_row<MODEL, false>(u, c0[i], Mdl::template prepare<false>(c0[i], Mdl::uses_c1 ? c1[i] : 0.0, Mdl::uses_c2 ? c2[i] : 0.0), f0, j);
+    jac[3 * (size_t)i] = j[0];
+    jac[3 * (size_t)i + 1] = j[1];
+    jac[3 * (size_t)i + 2] = j[2];
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -519,6 +544,7 @@ static int stream_fit_attempt(const StreamFitArgs &a, bool fast, bool *retry_exa
   } else {
     BcMachine<kM> &m = h.m[0].bc;
     m.start(a.p, a.n, a.lb, a.ub, a.dscl, a.itmax, a.opts, a.covar != nullptr, pg_candidates());
+    m.c.analytic_jac = a.analytic ? 1 : 0;
     if (m.h.req.kind == RQ_DONE) {
       switch (m.c.bad_input) {
       case 1: set_error("dlevmar_bc_dif(): cannot solve a problem with fewer measurements [%d] than unknowns [%d]", a.n, kM); break;
@@ -660,6 +686,29 @@ int stream_fit_run(const StreamFitArgs &a) {
     ret = stream_fit_attempt(a, false, &retry);
   }
   return ret;
+}
+
+int model_jac_run(int model, const double *d_angles, int n, const double *p, double *d_jac, hipStream_t stream) {
+  if (model < 0 || model >= MODEL_COUNT || !d_angles || !d_jac || !p || n <= 0) {
+    set_error("model_jac: bad arguments");
+    return kLmError;
+  }
+  (void)hipGetLastError();
+  Request<kM> r;
+  memset(&r, 0, sizeof r);
+  r.kind = RQ_JAC;
+  r.scal = 1.0;
+  for (int i = 0; i < kM; ++i) r.p[i] = p[i];
+  int blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  const double *c0 = d_angles, *c1 = d_angles + n, *c2 = d_angles + 2 * (size_t)n;
+  switch (model) {
+  case 0: hipLaunchKernelGGL(model_jac_kernel<0>, dim3(blocks), dim3(256), 0, stream, c0, c1, c2, n, r, d_jac); break;
+  case 1: hipLaunchKernelGGL(model_jac_kernel<1>, dim3(blocks), dim3(256), 0, stream, c0, c1, c2, n, r, d_jac); break;
+  default: hipLaunchKernelGGL(model_jac_kernel<2>, dim3(blocks), dim3(256), 0, stream, c0, c1, c2, n, r, d_jac); break;
+  }
+  HIP_OK(hipGetLastError());
+  return 0;
 }
 
 int model_eval_run(int model, const double *d_angles, int n, const double *p, double *d_hx, hipStream_t stream) {

@@ -9,7 +9,7 @@ import numpy as np
 from ._lib import D, ExtraData, last_error, lib
 
 MODEL_PHONG, MODEL_BLINN_PHONG, MODEL_WARD = 0, 1, 2
-METHOD_DIF, METHOD_BC_DIF = 0, 1
+METHOD_DIF, METHOD_BC_DIF, METHOD_BC_DER = 0, 1, 2  # 2: dlevmar_bc_der with the model's analytic Jacobian
 
 
 @dataclass
@@ -174,10 +174,36 @@ def host_dlevmar(method: int, model: int, angles: np.ndarray, x: np.ndarray, p0,
     if method == METHOD_DIF:
         ret = lib.dlevmar_dif(func, _dptr(p), _dptr(x), 3, n, itmax, _dptr(op_a), _dptr(info), None, _dptr(covar),
                               C.byref(ed))
+    elif method == METHOD_BC_DER:  # dlevmar_bc_der(BRDFFunc_hip, BRDFJac_hip, ...): the analytic Jacobian, all on the device
+        ret = lib.dlevmar_bc_der(func, C.cast(lib.BRDFJac_hip, C.c_void_p), _dptr(p), _dptr(x), 3, n, _dptr(lb_a), _dptr(ub_a),
+                                 _dptr(ds_a), itmax, _dptr(op_a), _dptr(info), None, _dptr(covar), C.byref(ed))
     else:
         ret = lib.dlevmar_bc_dif(func, _dptr(p), _dptr(x), 3, n, _dptr(lb_a), _dptr(ub_a), _dptr(ds_a), itmax,
                                  _dptr(op_a), _dptr(info), None, _dptr(covar), C.byref(ed))
     return FitResult(ret, p, info, None if covar is None else covar.reshape(3, 3))
+
+
+def model_jacobian(model: int, angles: np.ndarray, p) -> np.ndarray:
+    """BRDFJac_hip through host pointers: the analytic Jacobian [n, 3] of a built-in model."""
+    a = np.ascontiguousarray(angles, dtype=np.float64).reshape(-1)
+    n = a.size // 3
+    jac = np.zeros(3 * n)
+    pa = _f64(p, 3).copy()
+    ed = ExtraData(_dptr(a), model)
+    lib.BRDFJac_hip(_dptr(pa), _dptr(jac), 3, n, C.byref(ed))
+    return jac.reshape(n, 3)
+
+
+def chkjac(model: int, angles: np.ndarray, p) -> np.ndarray:
+    """dlevmar_chkjac (misc_core.c:250-321) on BRDFFunc_hip / BRDFJac_hip: err[n], ~1 where the Jacobian row is right."""
+    a = np.ascontiguousarray(angles, dtype=np.float64).reshape(-1)
+    n = a.size // 3
+    err = np.zeros(n)
+    pa = _f64(p, 3).copy()
+    ed = ExtraData(_dptr(a), model)
+    lib.dlevmar_chkjac(C.cast(lib.BRDFFunc_hip, C.c_void_p), C.cast(lib.BRDFJac_hip, C.c_void_p), _dptr(pa), 3, n, C.byref(ed),
+                       _dptr(err))
+    return err
 
 
 def last_fit_stats() -> dict:

@@ -37,7 +37,8 @@ struct brdf_extra_data {
 };
 
 enum { BRDF_MODEL_PHONG = 0, BRDF_MODEL_BLINN_PHONG = 1, BRDF_MODEL_WARD = 2 };
-enum { BRDF_METHOD_DIF = 0, BRDF_METHOD_BC_DIF = 1 };
+enum { BRDF_METHOD_DIF = 0, BRDF_METHOD_BC_DIF = 1,
+       BRDF_METHOD_BC_DER = 2 /* brdf_hip_fit_dev only: dlevmar_bc_der with the model's analytic Jacobian */ };
 
 /* ---- drop-in solver entry points ----------------------------------------------------------------- */
 
@@ -90,6 +91,19 @@ int brdf_hip_unregister_model(void (*func)(double *p, double *hx, int m, int n, 
 /* A BRDFFunc-compatible callback evaluated on the GPU (kernel K1 alone): hx[i] = model(p; sample i).
  * Replaces BRDFFunc, brdfdata.cpp:969-989; always treated as registered. */
 void BRDFFunc_hip(double *p, double *hx, int m, int n, void *adata);
+
+/* The analytic Jacobian of the built-in models in levmar's jacf form (n x 3, row-major), evaluated on the GPU
+ * (the reference only ever differentiates BRDFFunc numerically).  Passing it as `jacf` to
+ * dlevmar_bc_der together with a registered `func` keeps the whole fit on the device (RQ_JAC passes then cost one
+ * transcendental per sample instead of two and count no function evaluations, lmbc_core.c:1119-1124). */
+void BRDFJac_hip(double *p, double *jac, int m, int n, void *adata);
+
+/* Replaces dlevmar_chkjac, levmar/levmar.h:361-364 (body misc_core.c:250-321): err[i] near 1 where row i of jacf's
+ * Jacobian agrees with func, near 0 where it does not.  func/jacf run on the host (caller's code), the comparison of
+ * the n rows runs on the device. */
+void dlevmar_chkjac(void (*func)(double *p, double *hx, int m, int n, void *adata),
+                    void (*jacf)(double *p, double *j, int m, int n, void *adata), double *p, int m, int n, void *adata,
+                    double *err);
 
 /* ---- device-resident and batched entry points (extensions; the reference has no batched call) ----- */
 

@@ -54,3 +54,51 @@ void orc_brdf_func(double *p, double *hx, int m, int n, void *adata)
     break;
   }
 }
+
+/* Analytic Jacobian of the three models, n x 3 row-major like every levmar jacf (NOT in
+ * the reference, which only ever differentiates numerically; checked with the reference's own dlevmar_chkjac in
+ * tests/test_oracle_brdf.py).  Same sub-expressions, same order as orc_brdf_func. */
+void orc_brdf_jac(double *p, double *jac, int m, int n, void *adata)
+{
+  const struct orc_extra_data *d = (const struct orc_extra_data *)adata;
+  const double *c_ln = d->angles, *c_nh = d->angles + n, *c_p2 = d->angles + 2 * n;
+  int i;
+  (void)m;
+  switch (d->modelInfo) {
+  case 0: {
+    const double A = (p[2] + 2.0) / 2.0 * ORC_PI, dA = (1.0 / 2.0 * ORC_PI) * p[1], b = A * p[1];
+    for (i = 0; i < n; ++i) {
+      const double s = pow(c_p2[i], p[2]), lc = log(c_p2[i]);
+      jac[3 * i] = c_ln[i];
+      jac[3 * i + 1] = A * s;
+      jac[3 * i + 2] = dA * s + (b * s) * lc;
+    }
+    break;
+  }
+  case 1:
+    for (i = 0; i < n; ++i) {
+      const double s = pow(c_nh[i], p[2]), lc = log(c_nh[i]);
+      jac[3 * i] = c_ln[i];
+      jac[3 * i + 1] = s;
+      jac[3 * i + 2] = (p[1] * s) * lc;
+    }
+    break;
+  case 2: {
+    const double a2 = p[2] * p[2], ia2 = 1.0 / a2, k = 1.0 / (4.0 * ORC_PI * a2), two_over = 2.0 / p[2];
+    for (i = 0; i < n; ++i) {
+      const double ci = c_ln[i], ch = c_nh[i], co = c_p2[i];
+      const double ch2 = ch * ch;
+      const double t2 = (1.0 - ch2) / ch2;
+      const double rinv = 1.0 / sqrt(ci * co);
+      const double g = exp(-(t2 * ia2));
+      const double spec = (k * g) * rinv;
+      jac[3 * i] = ci / ORC_PI;
+      jac[3 * i + 1] = ci * spec;
+      jac[3 * i + 2] = ci * ((p[1] * spec) * (two_over * (t2 * ia2 - 1.0)));
+    }
+    break;
+  }
+  default:
+    break;
+  }
+}

@@ -42,6 +42,7 @@ struct orc_extra_data {
 };
 
 void orc_brdf_func(double *p, double *hx, int m, int n, void *adata);
+void orc_brdf_jac(double *p, double *jac, int m, int n, void *adata); /* analytic, n x 3 row-major; not in the reference */
 
 double orc_l2_residual(double *e, const double *x, const double *y, int n);
 void orc_fdif_forward(orc_func_t f, double *p, const double *hx, double *hxx, double delta,
@@ -65,7 +66,8 @@ int orc_dlevmar_bc_dif(orc_func_t f, double *p, double *x, int m, int n, double 
                        double *covar, void *adata);
 
 /* convenience for ctypes callers: one BRDF fit with the reference call-site conventions
- * (brdfdata.cpp:1085-1119).  method 0 = dlevmar_dif, 1 = dlevmar_bc_dif. Returns the solver's return. */
+ * (brdfdata.cpp:1085-1119).  method 0 = dlevmar_dif, 1 = dlevmar_bc_dif, 2 = dlevmar_bc_der with orc_brdf_jac.
+ * Returns the solver's return. */
 int orc_brdf_fit(int method, int model, double *angles, double *x, int n, double *p, int itmax,
                  double *opts, double *lb, double *ub, double *info);
 

@@ -18,6 +18,8 @@ int ref_brdf_fit(int method, int model, double *angles, double *x, int n, double
   d.modelInfo = model;
   if (method == 0)
     return dlevmar_dif(orc_brdf_func, p, x, 3, n, itmax, opts, info, 0, 0, &d);
+  if (method == 2) /* the reference's dlevmar_bc_der driven by our analytic Jacobian */
+    return dlevmar_bc_der(orc_brdf_func, orc_brdf_jac, p, x, 3, n, lb, ub, 0, itmax, opts, info, 0, 0, &d);
   return dlevmar_bc_dif(orc_brdf_func, p, x, 3, n, lb, ub, 0, itmax, opts, info, 0, 0, &d);
 }
 
@@ -32,4 +34,13 @@ int ref_brdf_fit_batch(int method, int model, double *angles, double *x, int S, 
                      lb, ub, info + 10 * s) < 0)
       ++bad;
   return bad;
+}
+
+/* the reference's own dlevmar_chkjac (misc_core.c:250-321) on the BRDF callbacks: err[n] */
+void ref_brdf_chkjac(int model, double *angles, int n, double *p, double *err)
+{
+  struct orc_extra_data d;
+  d.angles = angles;
+  d.modelInfo = model;
+  dlevmar_chkjac(orc_brdf_func, orc_brdf_jac, p, 3, n, &d, err);
 }

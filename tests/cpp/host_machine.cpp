@@ -44,9 +44,11 @@ struct HostPasses {
       for (int j = 0; j <= i; ++j) s[c++] = jtj[i * 3 + j];
   }
 
+  bool analytic = false;  // dlevmar_bc_der: RQ_JAC rows from the model's analytic Jacobian
+
   void run(const Request<3> &r, double *s, double &mx) {
     PassUniforms<MODEL> u;
-    u.build(r);
+    u.build(r, true, analytic);
     mx = 0.0;
     std::vector<double> f(n);
     double jtj[9], jte[3];
@@ -76,7 +78,10 @@ struct HostPasses {
     case RQ_JAC: {
       for (int i = 0; i < n; ++i) {
         double f0 = 0.0;
-        model_fd_row<MODEL, FAST>(u, c0[i], prep(i), true, f0, 0.0, false, &jac[3 * i]);
+        if (analytic)
+          model_an_row<MODEL, FAST>(u, c0[i], prep(i), f0, &jac[3 * i]);
+        else
+          model_fd_row<MODEL, FAST>(u, c0[i], prep(i), true, f0, 0.0, false, &jac[3 * i]);
         f[i] = f0;
       }
       s[SumLayout<3>::NL + 3] = orc_l2_residual(e.data(), x, f.data(), n);
@@ -172,8 +177,10 @@ int fit(int method, double *angles, double *x, int n, double *p, int itmax, doub
     return m.c.ret;
   }
   HostPasses<MODEL, FAST> hp(angles, x, n, 1);
+  hp.analytic = (method == 2);
   BcMachine<3> m;
   m.start(p, n, lb, ub, dscl, itmax, opts, covar != nullptr, g_multi);
+  m.c.analytic_jac = (method == 2) ? 1 : 0;
   while (m.h.req.kind != RQ_DONE) {
     hp.run(m.h.req, s, mx);
     ++np;

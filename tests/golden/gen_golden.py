@@ -1,7 +1,7 @@
 """Regenerates tests/golden/*.json from the REFERENCE itself (oracle/_ref = levmar 2.6 compiled from
 /root/reference/levmar in this container) -- run here, where the reference exists; the JSON travels.
 
-  brdf_fits.json   p[3] + info[10] + return value of the reference's dlevmar_dif / dlevmar_bc_dif driving
+  brdf_fits.json   p[3] + info[10] + return value of the reference's dlevmar_dif / dlevmar_bc_dif / dlevmar_bc_der driving
                    the BRDF callback on the seeded synthetic sets of brdf_amd/synth.py (inputs are
                    regenerated from the seed, not stored).  This pins the fits no reference-owned test pins.
   lmdemo_kat.json  the reference's own known answers: lmdemo.c problems run through the compiled
@@ -31,7 +31,7 @@ def main():
     for n in (16, 64, 341, 342, 1000, 10000):
         for model in (0, 1, 2):
             angles, x, _ = synth.make_single(model, n)
-            for method in (0, 1):
+            for method in (0, 1, 2):  # 2 = the reference's dlevmar_bc_der driven by the analytic Jacobian (f3)
                 r, p, info = L.brdf_fit("ref", method, model, angles, x, synth.P0[model], synth.ITMAX, synth.OPTS,
                                         synth.LB, synth.UB)
                 fits.append({"n": n, "model": model, "method": method, "ret": int(r), "p": [float.hex(v) for v in p],

@@ -337,6 +337,45 @@ def test_resident_regime_falls_back_when_a_workgroup_never_arrives(gpu, monkeypa
     assert brdf_amd.last_fit_stats()["launches"] == 1  # and the resident regime works again afterwards (tags restarted)
 
 
+@pytest.mark.parametrize("model", [0, 1, 2])
+def test_bc_der_with_the_analytic_device_jacobian(gpu, model, monkeypatch):
+    """dlevmar_bc_der with the built-in models' analytic Jacobian, entirely on the device
+    (brdf_hip_fit_dev method 2, and the drop-in dlevmar_bc_der(BRDFFunc_hip, BRDFJac_hip, ...)), in both single-fit
+    regimes, against the oracle's dlevmar_bc_der (bit-identical to the compiled reference's on the fixtures)"""
+    torch, brdf_amd, dev = gpu
+    lb, ub = synth.bounds(model)
+    for n in (1000, 100003):
+        angles, x, _ = synth.make_single(model, n)
+        _, p_ref, info_ref = L.brdf_fit("orc", 2, model, angles, x, synth.P0[model], synth.ITMAX, synth.OPTS, lb, ub)
+        for env in ("1", "0"):
+            monkeypatch.setenv("BRDF_HIP_RESIDENT", env)
+            res = _dev_fit(gpu, 2, model, angles, x, lb=lb, ub=ub)
+            _check(res, p_ref, info_ref)
+            assert res.info[8] == brdf_amd.last_fit_stats()["jac_passes"]  # one pass per Jacobian
+        res = brdf_amd.host_dlevmar(2, model, angles, x, synth.P0[model], lb=lb, ub=ub, itmax=synth.ITMAX, opts=synth.OPTS)
+        _check(res, p_ref, info_ref)
+    # BRDFJac_hip and dlevmar_chkjac through host pointers
+    angles, _, _ = synth.make_single(model, 3000)
+    p = np.array(synth.TRUTH[model])
+
+    class Extra(C.Structure):
+        _fields_ = [("angles", L.D), ("modelInfo", C.c_int)]
+
+    flat = np.ascontiguousarray(angles.reshape(-1))
+    jac_ref = np.zeros(9000)
+    L.orc.orc_brdf_jac(L.ptr(p.copy()), L.ptr(jac_ref), 3, 3000, C.byref(Extra(L.ptr(flat), model)))
+    jac = brdf_amd.model_jacobian(model, angles, p)
+    assert np.max(np.abs(jac.reshape(-1) - jac_ref)) <= 1e-13 * max(1.0, np.max(np.abs(jac_ref)))
+    err = brdf_amd.chkjac(model, angles, p)
+    assert err.min() > 0.5 and err.mean() > 0.99
+    if L.ref is not None:
+        err_ref = np.zeros(3000)
+        L.ref.ref_brdf_chkjac(model, L.ptr(flat), 3000, L.ptr(p.copy()), L.ptr(err_ref))
+        # err is a log10 of the rounding noise of a difference quotient: ocml's pow and glibc's differ in the last bits,
+        # so the two err vectors agree in what they say (row correct), not digit for digit
+        assert err_ref.min() > 0.5 and np.max(np.abs(err - err_ref)) <= 0.1
+
+
 def test_diagonal_scaling_and_nan_input(gpu):
     """dscl (lmbc_core.c:536-540, :555-569) and the stop-reason-7 path (non-finite function values ->
     LM_ERROR, lm_core.c:562, :749; lmbc_core.c:534)"""

@@ -1,5 +1,6 @@
 """BRDF fits: the oracle and the host-driven product state machines against the committed fixture that the
 REFERENCE solver produced (tests/golden/brdf_fits.json), bit for bit.  Inputs come from the seeded generator."""
+import ctypes as C
 import json
 import os
 
@@ -19,7 +20,7 @@ def _hex(v):
 
 
 def _id(f):
-    return f"n{f['n']}-model{f['model']}-{'dif' if f['method'] == 0 else 'bc_dif'}"
+    return f"n{f['n']}-model{f['model']}-{('dif', 'bc_dif', 'bc_der')[f['method']]}"
 
 
 @pytest.mark.parametrize("fit", FITS, ids=_id)
@@ -157,3 +158,31 @@ def test_multi_candidate_projected_gradient_is_bit_exact(k):
             assert r == f["ret"] and np.array_equal(p, _hex(f["p"])) and np.array_equal(info, _hex(f["info"]))
     finally:
         L.hm.hm_set_bc_multi(1)
+
+
+@pytest.mark.parametrize("model", [0, 1, 2])
+def test_analytic_jacobian_passes_the_references_own_chkjac(model):
+    """the analytic Jacobian is ours (the reference only differentiates numerically), so
+    it is judged by the reference's dlevmar_chkjac (misc_core.c:250-321, compiled from /root/reference) and against
+    central differences of the restated callback"""
+    angles, _, _ = synth.make_single(model, 2000)
+    a = L.f64(angles)
+    p = L.f64(synth.TRUTH[model]).copy()
+    if L.ref is not None:
+        err = np.zeros(2000)
+        L.ref.ref_brdf_chkjac(model, L.ptr(a), 2000, L.ptr(p), L.ptr(err))
+        assert err.min() > 0.5 and err.mean() > 0.99
+
+    class Extra(C.Structure):
+        _fields_ = [("angles", L.D), ("modelInfo", C.c_int)]
+
+    jac = np.zeros(3 * 2000)
+    L.orc.orc_brdf_jac(L.ptr(p), L.ptr(jac), 3, 2000, C.byref(Extra(L.ptr(a), model)))
+    jac = jac.reshape(2000, 3)
+    for j in range(3):
+        h = 1e-6 * max(1.0, abs(p[j]))
+        pp, pm = p.copy(), p.copy()
+        pp[j] += h
+        pm[j] -= h
+        fd = (L.model_values(model, angles, pp) - L.model_values(model, angles, pm)) / (2 * h)
+        assert np.max(np.abs(fd - jac[:, j])) <= 1e-6 * max(1.0, np.max(np.abs(jac[:, j])))
