@@ -22,6 +22,26 @@ struct BatchFitArgs {
 };
 int batch_fit_enqueue(const BatchFitArgs &a);
 
+constexpr int kNeedsExact = -2;  // flag value: this fit has a cosine <= 0 and must take the exact model path
+
+struct BatchCtx {
+  const double *angles;  // [S][3][n]
+  const double *x;       // [S][n]
+  double *p;             // [S][3] in/out
+  double *info;          // [S][10] or null
+  int *ret;              // [S] or null
+  int *flags;            // [S] internal: kNeedsExact marks fits handed to the exact kernel
+  int S, n, itmax;
+  int has_opts, has_lb, has_ub;
+  int multi;  // bc_dif: projected-gradient candidates per sweep (workgroup/wave-per-fit kernels)
+  double opts[5], lb[kM], ub[kM];
+};
+
+// 1024 < n <= 4096 samples per fit: one workgroup per fit, control wave + seven sample waves (resident_fit.hip).
+// fast = false: only the fits whose flag is kNeedsExact are fitted (exact model path)
+int resident_batch_enqueue(int model, int method, bool fast, const BatchCtx &c, hipStream_t stream);
+
+
 int synth_enqueue(int model, unsigned long long seed, long long first, int count, int n, const double *d_truth,
                   double *d_angles, double *d_x, hipStream_t stream);
 

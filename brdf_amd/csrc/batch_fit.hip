@@ -18,21 +18,6 @@
 
 namespace brdf {
 
-constexpr int kNeedsExact = -2;  // flag value: this fit has a cosine <= 0 and must take the exact model path
-
-struct BatchCtx {
-  const double *angles;  // [S][3][n]
-  const double *x;       // [S][n]
-  double *p;             // [S][3] in/out
-  double *info;          // [S][10] or null
-  int *ret;              // [S] or null
-  int *flags;            // [S] internal: kNeedsExact marks fits handed to the exact kernel
-  int S, n, itmax;
-  int has_opts, has_lb, has_ub;
-  int multi;  // bc_dif: projected-gradient candidates per sweep (workgroup/wave-per-fit kernels)
-  double opts[5], lb[kM], ub[kM];
-};
-
 template <int METHOD>
 using BatchMachine = typename std::conditional<METHOD == 0, DifMachine<kM>, BcMachine<kM>>::type;
 
@@ -568,6 +553,12 @@ int rows_enqueue(const BatchFitArgs &a, const BatchCtx &c, bool fast) {
 
 }  // namespace
 
+// BRDF_HIP_BATCH_BIG=0: the symmetric 512 x 8 geometry of this file instead of the control-wave kernel for 1024 < n <= 4096
+static bool big_path_enabled() {
+  const char *e = getenv("BRDF_HIP_BATCH_BIG");
+  return !(e && e[0] == '0');
+}
+
 int batch_fit_enqueue(const BatchFitArgs &a) {
   if (a.model < 0 || a.model >= MODEL_COUNT || (a.method != 0 && a.method != 1)) {
     set_error("brdf_hip_fit_batch_dev(): unknown model %d / method %d", a.model, a.method);
@@ -631,6 +622,11 @@ int batch_fit_enqueue(const BatchFitArgs &a) {
 
   const bool fast = brdf_fast_path_enabled() || a.model == MODEL_WARD;
   if (a.n <= kRowLanes && rows_path_enabled()) return rows_enqueue(a, c, fast);
+  if (g.threads == 512 && big_path_enabled()) {  // 1024 < n <= 4096: control wave + seven sample waves per fit (resident_fit.hip)
+    c.multi = pg_candidates();
+    if (!fast) HIP_OK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(fb.ptr), kNeedsExact, (size_t)a.S, a.stream));
+    return resident_batch_enqueue(a.model, a.method, fast, c, a.stream);
+  }
   const dim3 grid(a.S), block(g.threads);
   if (fast) {
     hipLaunchKernelGGL(kernel_for(g, a.model, a.method, true), grid, block, 0, a.stream, c);

@@ -37,6 +37,7 @@
 #include <cstring>
 #include <type_traits>
 
+#include "batch_fit.h"
 #include "stream_fit.h"
 
 namespace brdf {
@@ -267,8 +268,11 @@ __device__ __forceinline__ bool control_exchange(const ResidentCtx &ctx, unsigne
   return true;
 }
 
-template <int MODEL, int METHOD, bool FAST>
-__global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx) {
+// BATCHED = false: one fit spread over the grid (ctx).  BATCHED = true: one workgroup per fit of 1024 < n <= 4096 samples
+// (bctx, batch_fit.h) -- the same control wave / sample waves / LDS Jacobian, no exchange between workgroups, the
+// speculative dlevmar_dif protocol (one pass per LM iteration), the machine started on the device.
+template <int MODEL, int METHOD, bool FAST, bool BATCHED>
+__global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx, BatchCtx bctx) {
   using Machine = RMachine<METHOD>;
   using Mdl = BrdfModel<MODEL>;
   static_assert(sizeof(Machine) % 4 == 0, "machine copied as dwords");
@@ -277,22 +281,35 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
   __shared__ double red[kSlots * kRedCols];
   __shared__ double sums[kSlots];
   __shared__ double dp_prev[kM + 1];  // Dp and ||Dp||^2 of the last trial (dif)
-  __shared__ int s_abort;
+  __shared__ int s_abort, s_bad;
   constexpr int kJl = (METHOD == 0) ? 3 * kRCap : 2;
   __shared__ double jl[kJl];  // dif: the secant Jacobian, SoA planes
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  const int G = gridDim.x;
-  const int n = ctx.n;
+  const int G = BATCHED ? 1 : (int)gridDim.x;
+  const int n = BATCHED ? bctx.n : ctx.n;
+  const int fit = blockIdx.x;  // BATCHED only
+  if constexpr (BATCHED && !FAST) {
+    if (bctx.flags[fit] != kNeedsExact) return;  // exact kernel: only the fits the fast kernel declined
+  }
 
-  {  // the started machine, written by the host before the launch
+  if constexpr (BATCHED) {  // the machine is started here (all 64 lanes of the control wave, identical values)
+    if (wave == 0) {
+      const double *p0 = bctx.p + (size_t)fit * kM;
+      const double *opts = bctx.has_opts ? bctx.opts : nullptr;
+      if constexpr (METHOD == 0)
+        sm.start(p0, n, bctx.itmax, opts, 0, /*speculative=*/1);
+      else
+        sm.start(p0, n, bctx.has_lb ? bctx.lb : nullptr, bctx.has_ub ? bctx.ub : nullptr, nullptr, bctx.itmax, opts, 0, bctx.multi);
+    }
+  } else {  // the started machine, written by the host before the launch
     const unsigned *src = reinterpret_cast<const unsigned *>(ctx.machine0);
     unsigned *dst = reinterpret_cast<unsigned *>(&sm);
     for (int w = tid; w < (int)(sizeof(Machine) / 4); w += kRThreads) dst[w] = src[w];
-    if (tid == 0) s_abort = 0;
-    if (tid <= kM) dp_prev[tid] = 0.0;
   }
+  if (tid == 0) s_abort = s_bad = 0;
+  if (tid <= kM) dp_prev[tid] = 0.0;
   __syncthreads();
   if (wave == 0) {
     if constexpr (METHOD == 1)
@@ -317,13 +334,32 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
       __syncthreads();  // X1 (worker_reduce)
       __syncthreads();  // X2: sums[] hold this workgroup's partial sums
       RSTAMP(1);
-      bool alive;
-      switch (kind) {
-      case RQ_JAC: alive = control_exchange<SumLayout<kM>::JAC>(ctx, epoch, sums, &s_abort, st_, last_); break;
-      case RQ_DIF_JAC: alive = control_exchange<SumLayout<kM>::DIF_JAC>(ctx, epoch, sums, &s_abort, st_, last_); break;
-      case RQ_DIF_TRIAL: alive = control_exchange<SumLayout<kM>::DIF_TRIAL>(ctx, epoch, sums, &s_abort, st_, last_); break;
-      case RQ_EVAL_MULTI: alive = control_exchange<kMaxCand>(ctx, epoch, sums, &s_abort, st_, last_); break;
-      default: alive = control_exchange<1>(ctx, epoch, sums, &s_abort, st_, last_); break;
+      bool alive = true;
+      if constexpr (BATCHED && FAST) {  // the sample waves looked at the cosines while loading the tile (before X1)
+        if (epoch == 0) {
+          if (s_bad) {  // log of a non-positive cosine: leave this fit to the exact kernel
+            if (tid == 0) bctx.flags[fit] = kNeedsExact;
+            s_abort = 1;
+            alive = false;
+          } else if (tid == 0) {
+            bctx.flags[fit] = 0;
+          }
+        }
+      }
+      if constexpr (!BATCHED) {  // (a batched fit is one workgroup: sums[] already hold everything)
+        if constexpr (METHOD == 0) {
+          switch (kind) {
+          case RQ_DIF_JAC: alive = control_exchange<SumLayout<kM>::DIF_JAC>(ctx, epoch, sums, &s_abort, st_, last_); break;
+          case RQ_DIF_TRIAL: alive = control_exchange<SumLayout<kM>::DIF_TRIAL>(ctx, epoch, sums, &s_abort, st_, last_); break;
+          default: alive = control_exchange<1>(ctx, epoch, sums, &s_abort, st_, last_); break;
+          }
+        } else {
+          switch (kind) {
+          case RQ_JAC: alive = control_exchange<SumLayout<kM>::JAC>(ctx, epoch, sums, &s_abort, st_, last_); break;
+          case RQ_EVAL_MULTI: alive = control_exchange<kMaxCand>(ctx, epoch, sums, &s_abort, st_, last_); break;
+          default: alive = control_exchange<1>(ctx, epoch, sums, &s_abort, st_, last_); break;
+          }
+        }
       }
       if (!alive) {  // give up: the host sees no `done`, reads ctl->abort and falls back
         __syncthreads();  // B (the sample waves read s_abort behind it)
@@ -343,6 +379,16 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
       }
       __syncthreads();  // B: the next request and its uniforms are in LDS
       RSTAMP(4);
+    }
+    if constexpr (BATCHED) {
+      if (tid == 0) {
+        double *po = bctx.p + (size_t)fit * kM;
+        for (int i = 0; i < kM; ++i) po[i] = sm.h.p[i];
+        if (bctx.info)
+          for (int i = 0; i < kInfoSz; ++i) bctx.info[(size_t)fit * kInfoSz + i] = sm.c.info[i];
+        if (bctx.ret) bctx.ret[fit] = sm.c.ret;
+      }
+      return;
     }
     if (blockIdx.x == 0 && tid == 0) {  // every workgroup holds the same finished machine; workgroup 0 reports
       Mailbox *mb = ctx.mbox;
@@ -369,11 +415,15 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
 
   // ============================= sample waves: the resident tile and the sweeps ================================
   const int wt = tid - kWave;  // 0..447
-  int vb = blockIdx.x;         // same XCD-contiguous dealing of tiles as the launch chain
-  if ((G & 7) == 0) vb = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+  int vb = BATCHED ? 0 : (int)blockIdx.x;  // same XCD-contiguous dealing of tiles as the launch chain
+  if (!BATCHED && (G & 7) == 0) vb = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
   const int tile = (n + G - 1) / G;  // <= kRTile, checked on the host
   const int begin = vb * tile;
   const int end = min(n, begin + tile);
+  const double *pc0 = BATCHED ? bctx.angles + (size_t)fit * 3 * n : ctx.c0;
+  const double *pc1 = BATCHED ? pc0 + n : ctx.c1;
+  const double *pc2 = BATCHED ? pc0 + 2 * (size_t)n : ctx.c2;
+  const double *px = BATCHED ? bctx.x + (size_t)fit * n : ctx.x;
   const int nk = (tile + kRWorkers - 1) / kRWorkers;  // occupied sample slots of a lane (workgroup-uniform)
   double s0[kRSpt], sx[kRSpt];
   Prep pq[kRSpt];
@@ -386,14 +436,18 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
       const bool ok = i < end;
       okm |= ok ? (1u << k) : 0u;
       const int ii = ok ? i : begin;
-      s0[k] = ctx.c0[ii];
-      const double r1 = Mdl::uses_c1 ? ctx.c1[ii] : 0.0;
-      const double r2 = Mdl::uses_c2 ? ctx.c2[ii] : 0.0;
-      sx[k] = ctx.x[ii];
+      s0[k] = pc0[ii];
+      const double r1 = Mdl::uses_c1 ? pc1[ii] : 0.0;
+      const double r2 = Mdl::uses_c2 ? pc2[ii] : 0.0;
+      sx[k] = px[ii];
       pq[k] = Mdl::template prepare<FAST>(s0[k], r1, r2);
       if (FAST && ok && !Mdl::domain_ok(s0[k], r1, r2)) bad = true;
     }
-    if (FAST && bad) __hip_atomic_store(&ctx.ctl->domain_bad, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if constexpr (BATCHED) {
+      if (FAST && bad) s_bad = 1;  // benign race: every writer stores 1
+    } else {
+      if (FAST && bad) __hip_atomic_store(&ctx.ctl->domain_bad, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   double hx[METHOD == 0 ? kRSpt : 1], wrk[METHOD == 0 ? kRSpt : 1];
   if constexpr (METHOD == 0) {
@@ -435,7 +489,8 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
     for (int k = 0; k < kSums; ++k) acc[k] = 0.0;
     double mx = 0.0;
     switch (kind) {
-    case RQ_EVAL:
+    case RQ_EVAL:  // (the four kinds only dlevmar_bc_dif / bc_der issue are compiled into those kernels only)
+      if constexpr (METHOD == 1) {
 #pragma unroll
       for (int k = 0; k < kRSpt; ++k) if (k < nk) {
         const double f = model_value<MODEL, FAST>(u, s0[k], pq[k]);
@@ -444,8 +499,10 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
         mx = fmax(mx, fabs(e));
       }
       worker_reduce<1>(acc, mx, red, sums);
+      }
       break;
     case RQ_SCALED:
+      if constexpr (METHOD == 1) {
 #pragma unroll
       for (int k = 0; k < kRSpt; ++k) if (k < nk) {
         const double f = model_value<MODEL, FAST>(u, s0[k], pq[k]);
@@ -453,8 +510,10 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
         acc[0] = fma(t, t, acc[0]);
       }
       worker_reduce<1>(acc, mx, red, sums);
+      }
       break;
     case RQ_EVAL_MULTI:
+      if constexpr (METHOD == 1) {
 #pragma unroll
       for (int k = 0; k < kRSpt; ++k) if (k < nk) {
 #pragma unroll
@@ -465,8 +524,10 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
           }
       }
       worker_reduce<kMaxCand>(acc, mx, red, sums);
+      }
       break;
     case RQ_JAC:
+      if constexpr (METHOD == 1) {
 #pragma unroll
       for (int k = 0; k < kRSpt; ++k) if (k < nk) {
         double f0 = 0.0, j[kM];
@@ -480,6 +541,7 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
         acc[kNL + kM] = fma(e, e, acc[kNL + kM]);
       }
       worker_reduce<SumLayout<kM>::JAC>(acc, mx, red, sums);
+      }
       break;
     case RQ_DIF_INIT:
       if constexpr (METHOD == 0) {
@@ -489,8 +551,8 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
           const double e = (okm >> k & 1u) ? sx[k] - hx[k] : 0.0;
           acc[0] = fma(e, e, acc[0]);
         }
+        worker_reduce<1>(acc, mx, red, sums);
       }
-      worker_reduce<1>(acc, mx, red, sums);
       break;
     case RQ_DIF_JAC:
       if constexpr (METHOD == 0) {
@@ -506,8 +568,8 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
           jl[2 * kRCap + s] = j[2];
           acc_normal_eq_fma(j, e, acc, acc + kNL);
         }
+        worker_reduce<SumLayout<kM>::DIF_JAC>(acc, mx, red, sums);
       }
-      worker_reduce<SumLayout<kM>::DIF_JAC>(acc, mx, red, sums);
       break;
     case RQ_DIF_TRIAL:  // speculative protocol: the Broyden-updated row is formed for the sums only; J itself is
                         // updated (from wrk, hx) at the top of the next pass if the machine adopts it
@@ -533,8 +595,8 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
           acc[1 + kNL + kM + 1] = fma(jn[1], eo, acc[1 + kNL + kM + 1]);
           acc[1 + kNL + kM + 2] = fma(jn[2], eo, acc[1 + kNL + kM + 2]);
         }
+        worker_reduce<SumLayout<kM>::DIF_TRIAL>(acc, mx, red, sums);
       }
-      worker_reduce<SumLayout<kM>::DIF_TRIAL>(acc, mx, red, sums);
       break;
     default:  // unknown request: keep the barrier protocol, the control wave will not survive it either
       worker_reduce<1>(acc, mx, red, sums);
@@ -645,7 +707,7 @@ int resident_attempt(const StreamFitArgs &a, RWorkspace &ws, bool *retry_exact, 
   if (const char *e = getenv("BRDF_HIP_RESIDENT_SPIN_MS")) c.spin_ticks = std::max(1LL, atoll(e)) * 100000LL;
   if (const char *e = getenv("BRDF_HIP_RESIDENT_SABOTAGE")) c.sabotage_epoch = atoi(e);  // tests only: forces the fallback
 
-  hipLaunchKernelGGL((resident_fit_kernel<MODEL, METHOD, FAST>), dim3(G), dim3(kRThreads), 0, a.stream, c);
+  hipLaunchKernelGGL((resident_fit_kernel<MODEL, METHOD, FAST, false>), dim3(G), dim3(kRThreads), 0, a.stream, c, BatchCtx{});
   HIP_OK(hipGetLastError());
   {  // wait on the pinned mailbox (a stream synchronise sleeps and wakes up tens of microseconds late); the launch
      // always terminates (bounded spins), which hipStreamQuery reports even if `done` never comes
@@ -703,6 +765,34 @@ int resident_run_mm(const StreamFitArgs &a, RWorkspace &ws, bool *unavailable) {
 }  // namespace
 
 FitStats resident_fit_last_stats() { return g_rws.stats; }
+
+namespace {
+template <int MODEL, int METHOD>
+int resident_batch_mm(bool fast, const BatchCtx &c, hipStream_t stream) {
+  const dim3 grid(c.S), block(kRThreads);
+  const ResidentCtx none{};
+  if (fast) {
+    hipLaunchKernelGGL((resident_fit_kernel<MODEL, METHOD, true, true>), grid, block, 0, stream, none, c);
+    HIP_OK(hipGetLastError());
+  }
+  if constexpr (MODEL != MODEL_WARD) {  // fits with a cosine <= 0 marked themselves (or all are marked: exact mode)
+    hipLaunchKernelGGL((resident_fit_kernel<MODEL, METHOD, false, true>), grid, block, 0, stream, none, c);
+    HIP_OK(hipGetLastError());
+  }
+  return 0;
+}
+}  // namespace
+
+int resident_batch_enqueue(int model, int method, bool fast, const BatchCtx &c, hipStream_t stream) {
+  switch (model * 2 + method) {
+  case 0: return resident_batch_mm<0, 0>(fast, c, stream);
+  case 1: return resident_batch_mm<0, 1>(fast, c, stream);
+  case 2: return resident_batch_mm<1, 0>(fast, c, stream);
+  case 3: return resident_batch_mm<1, 1>(fast, c, stream);
+  case 4: return resident_batch_mm<2, 0>(fast, c, stream);
+  default: return resident_batch_mm<2, 1>(fast, c, stream);
+  }
+}
 
 // returns true if the resident path handled the fit (*ret is then the solver's return value)
 bool resident_fit_try(const StreamFitArgs &a, int *ret) {
