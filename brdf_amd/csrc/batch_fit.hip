@@ -231,8 +231,11 @@ __global__ __launch_bounds__(THREADS, (batch_waves_per_simd<THREADS, SPT>())) vo
 constexpr int kRowLanes = 16;
 constexpr int kRowsPerWave = kWave / kRowLanes;
 
+// Occupancy, measured at n = 16 (2^18 fits): dlevmar_dif fits in 128 VGPRs with 39 spilled and still gains from four
+// waves per SIMD (1.65e7 vs 1.17e7 fits/s at two); dlevmar_bc_dif spills 138 VGPRs at that budget and is 4-8 % faster
+// with two waves per SIMD and none spilled.
 template <int MODEL, int METHOD, bool FAST>
-__global__ __launch_bounds__(kWave, 4) void batch_fit_rows_kernel(BatchCtx ctx, int *queue) {
+__global__ __launch_bounds__(kWave, (METHOD == 0 ? 4 : 2)) void batch_fit_rows_kernel(BatchCtx ctx, int *queue) {
   using Machine = BatchMachine<METHOD>;
   using Mdl = BrdfModel<MODEL>;
   __shared__ Machine sm[kRowsPerWave];
