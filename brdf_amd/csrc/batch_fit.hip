@@ -95,9 +95,10 @@ __global__ __launch_bounds__(THREADS, (batch_waves_per_simd<THREADS, SPT>())) vo
   }
   __syncthreads();
 
-  double hx[SPT], wrk[SPT], jac[SPT][kM];  // dif only: f(p), f(q) and the secant Jacobian rows of this lane's samples
+  constexpr int DS = (METHOD == 0) ? SPT : 1;
+  double hx[DS], wrk[DS], jac[DS][kM];  // dif only: f(p), f(q) and the secant Jacobian rows of this lane's samples
 #pragma unroll
-  for (int k = 0; k < SPT; ++k) {
+  for (int k = 0; k < DS; ++k) {
     hx[k] = wrk[k] = 0.0;
     jac[k][0] = jac[k][1] = jac[k][2] = 0.0;
   }
@@ -114,7 +115,8 @@ __global__ __launch_bounds__(THREADS, (batch_waves_per_simd<THREADS, SPT>())) vo
     double mx = 0.0;
 
     switch (kind) {
-    case RQ_EVAL:
+    case RQ_EVAL:  // (each kernel is compiled with the request kinds its entry point issues only: register pressure)
+      if constexpr (METHOD == 1) {
 #pragma unroll
       for (int k = 0; k < SPT; ++k) {
         const double f = model_value<MODEL, FAST>(u, s0[k], pq[k]);
@@ -123,9 +125,10 @@ __global__ __launch_bounds__(THREADS, (batch_waves_per_simd<THREADS, SPT>())) vo
         mx = fmax(mx, fabs(e));
       }
       block_reduce<1, THREADS>(acc, mx, red, sums);
+      }
       break;
     case RQ_EVAL_MULTI:
-      if constexpr (THREADS < 512) {  // the 512 x 8 geometry never asks for it (see batch_fit_enqueue): keeping the
+      if constexpr (METHOD == 1 && THREADS < 512) {  // the 512 x 8 geometry never asks for it (see batch_fit_enqueue): keeping the
                                        // unrolled 8 x 8 body out of that kernel keeps its samples in registers
 #pragma unroll
         for (int k = 0; k < SPT; ++k) {
@@ -140,6 +143,7 @@ __global__ __launch_bounds__(THREADS, (batch_waves_per_simd<THREADS, SPT>())) vo
       }
       break;
     case RQ_SCALED:
+      if constexpr (METHOD == 1) {
 #pragma unroll
       for (int k = 0; k < SPT; ++k) {
         const double f = model_value<MODEL, FAST>(u, s0[k], pq[k]);
@@ -147,8 +151,10 @@ __global__ __launch_bounds__(THREADS, (batch_waves_per_simd<THREADS, SPT>())) vo
         acc[0] += t * t;
       }
       block_reduce<1, THREADS>(acc, mx, red, sums);
+      }
       break;
     case RQ_JAC:
+      if constexpr (METHOD == 1) {
 #pragma unroll
       for (int k = 0; k < SPT; ++k) {
         double f0 = 0.0, j[kM];
@@ -159,8 +165,10 @@ __global__ __launch_bounds__(THREADS, (batch_waves_per_simd<THREADS, SPT>())) vo
         acc[kNL + kM] += e * e;
       }
       block_reduce<SumLayout<kM>::JAC, THREADS>(acc, mx, red, sums);
+      }
       break;
     case RQ_DIF_INIT:
+      if constexpr (METHOD == 0) {
 #pragma unroll
       for (int k = 0; k < SPT; ++k) {
         hx[k] = model_value<MODEL, FAST>(u, s0[k], pq[k]);
@@ -168,8 +176,10 @@ __global__ __launch_bounds__(THREADS, (batch_waves_per_simd<THREADS, SPT>())) vo
         acc[0] += e * e;
       }
       block_reduce<1, THREADS>(acc, mx, red, sums);
+      }
       break;
     case RQ_DIF_JAC:
+      if constexpr (METHOD == 0) {
 #pragma unroll
       for (int k = 0; k < SPT; ++k) {
         double f0 = 0.0;
@@ -179,8 +189,10 @@ __global__ __launch_bounds__(THREADS, (batch_waves_per_simd<THREADS, SPT>())) vo
         acc_normal_eq(jac[k], e, acc, acc + kNL);
       }
       block_reduce<SumLayout<kM>::DIF_JAC, THREADS>(acc, mx, red, sums);
+      }
       break;
     case RQ_DIF_TRIAL:  // two-step protocol: only f(q) and ||x - f(q)||^2
+      if constexpr (METHOD == 0) {
 #pragma unroll
       for (int k = 0; k < SPT; ++k) {
         wrk[k] = model_value_q<MODEL, FAST>(u, s0[k], pq[k]);
@@ -188,8 +200,10 @@ __global__ __launch_bounds__(THREADS, (batch_waves_per_simd<THREADS, SPT>())) vo
         acc[0] += e * e;
       }
       block_reduce<1, THREADS>(acc, mx, red, sums);
+      }
       break;
-    case RQ_DIF_UPDATE: {  // Broyden update in registers + normal equations of the updated Jacobian
+    case RQ_DIF_UPDATE:  // Broyden update in registers + normal equations of the updated Jacobian
+      if constexpr (METHOD == 0) {
       const bool accepted = sm.h.req.aux != 0;
 #pragma unroll
       for (int k = 0; k < SPT; ++k) {
@@ -204,8 +218,8 @@ __global__ __launch_bounds__(THREADS, (batch_waves_per_simd<THREADS, SPT>())) vo
         acc_normal_eq(jn, e, acc, acc + kNL);
       }
       block_reduce<SumLayout<kM>::DIF_JAC, THREADS>(acc, mx, red, sums);
+      }
       break;
-    }
     default: break;
     }
     if (first_wave) sm.template step<true>(sums, sums[kSums]);
