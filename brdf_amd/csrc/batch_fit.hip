@@ -38,6 +38,7 @@ __global__ __launch_bounds__(THREADS, (batch_waves_per_simd<THREADS, SPT>())) vo
   __shared__ double red[reduce_buf_doubles<THREADS>()];
   __shared__ double sums[kSlots];
   __shared__ int bad_domain;
+  __shared__ double dp_prev[kM + 1];  // dif: Dp and ||Dp||^2 of the last trial
 
   const int fit = blockIdx.x;
   const int tid = threadIdx.x;
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(THREADS, (batch_waves_per_simd<THREADS, SPT>())) vo
     const double *p0 = ctx.p + (size_t)fit * kM;
     const double *opts = ctx.has_opts ? ctx.opts : nullptr;
     if constexpr (METHOD == 0)
-      sm.start(p0, n, ctx.itmax, opts, 0, /*speculative=*/0);
+      sm.start(p0, n, ctx.itmax, opts, 0, /*speculative=*/1);
     else
       sm.start(p0, n, ctx.has_lb ? ctx.lb : nullptr, ctx.has_ub ? ctx.ub : nullptr, nullptr, ctx.itmax, opts, 0, ctx.multi);
   }
@@ -103,12 +104,33 @@ __global__ __launch_bounds__(THREADS, (batch_waves_per_simd<THREADS, SPT>())) vo
     jac[k][0] = jac[k][1] = jac[k][2] = 0.0;
   }
 
+  int cur_sel_hx = 0, cur_sel_j = 0;
   for (;;) {
     const int kind = sm.h.req.kind;
     if (kind == RQ_DONE) break;
-    if (first_wave) su.build(sm.h.req);
+    if (first_wave) su.build(sm.h.req, /*need_base=*/METHOD != 0);  // (dif keeps f(p) per sample: a trial evaluates f at q only)
     __syncthreads();
     const PassUniforms<MODEL> &u = su;
+    if constexpr (METHOD == 0) {  // commit what the machine decided about the previous trial (speculative protocol,
+                                  // one pass per LM iteration: lm_machine.h, DifMachine)
+      if (sm.h.req.sel_j != cur_sel_j) {  // adopt the Broyden update J += ((wrk - hx - J Dp)/||Dp||^2) Dp^T, lm_core.c:760-766
+        const double dpp[kM] = {dp_prev[0], dp_prev[1], dp_prev[2]};
+#pragma unroll
+        for (int k = 0; k < DS; ++k) {
+          double jn[kM];
+          broyden_row(jac[k], wrk[k], hx[k], dpp, dp_prev[kM], jn);
+          jac[k][0] = jn[0];
+          jac[k][1] = jn[1];
+          jac[k][2] = jn[2];
+        }
+        cur_sel_j = sm.h.req.sel_j;
+      }
+      if (sm.h.req.sel_hx != cur_sel_hx) {  // step accepted: hx <- f(p + Dp)
+#pragma unroll
+        for (int k = 0; k < DS; ++k) hx[k] = wrk[k];
+        cur_sel_hx = sm.h.req.sel_hx;
+      }
+    }
     double acc[kSums];
 #pragma unroll
     for (int k = 0; k < kSums; ++k) acc[k] = 0.0;
@@ -191,38 +213,36 @@ __global__ __launch_bounds__(THREADS, (batch_waves_per_simd<THREADS, SPT>())) vo
       block_reduce<SumLayout<kM>::DIF_JAC, THREADS>(acc, mx, red, sums);
       }
       break;
-    case RQ_DIF_TRIAL:  // two-step protocol: only f(q) and ||x - f(q)||^2
+    case RQ_DIF_TRIAL:  // speculative protocol: the Broyden-updated row is formed for the sums only; the rows
+                        // themselves are updated (from wrk, hx) at the top of the next pass if the machine adopts it
       if constexpr (METHOD == 0) {
 #pragma unroll
-      for (int k = 0; k < SPT; ++k) {
-        wrk[k] = model_value_q<MODEL, FAST>(u, s0[k], pq[k]);
-        const double e = ok[k] ? sx[k] - wrk[k] : 0.0;
-        acc[0] += e * e;
-      }
-      block_reduce<1, THREADS>(acc, mx, red, sums);
-      }
-      break;
-    case RQ_DIF_UPDATE:  // Broyden update in registers + normal equations of the updated Jacobian
-      if constexpr (METHOD == 0) {
-      const bool accepted = sm.h.req.aux != 0;
-#pragma unroll
-      for (int k = 0; k < SPT; ++k) {
-        double jn[kM];
-        broyden_row(jac[k], wrk[k], hx[k], u.dp, u.dp_l2, jn);
-        double e = sx[k] - (accepted ? wrk[k] : hx[k]);
-        if (!ok[k]) e = jn[0] = jn[1] = jn[2] = 0.0;
-        jac[k][0] = jn[0];
-        jac[k][1] = jn[1];
-        jac[k][2] = jn[2];
-        if (accepted) hx[k] = wrk[k];
-        acc_normal_eq(jn, e, acc, acc + kNL);
-      }
-      block_reduce<SumLayout<kM>::DIF_JAC, THREADS>(acc, mx, red, sums);
+        for (int k = 0; k < SPT; ++k) {
+          const double w = model_value_q<MODEL, FAST>(u, s0[k], pq[k]);
+          double jn[kM];
+          broyden_row(jac[k], w, hx[k], u.dp, u.dp_l2, jn);
+          double en = sx[k] - w, eo = sx[k] - hx[k];
+          if (!ok[k]) en = eo = jn[0] = jn[1] = jn[2] = 0.0;
+          wrk[k] = w;
+          acc[0] += en * en;
+          acc_normal_eq(jn, en, acc + 1, acc + 1 + kNL);
+          acc[1 + kNL + kM + 0] += jn[0] * eo;
+          acc[1 + kNL + kM + 1] += jn[1] * eo;
+          acc[1 + kNL + kM + 2] += jn[2] * eo;
+        }
+        block_reduce<SumLayout<kM>::DIF_TRIAL, THREADS>(acc, mx, red, sums);
       }
       break;
     default: break;
     }
-    if (first_wave) sm.template step<true>(sums, sums[kSums]);
+    if (first_wave) {
+      if (METHOD == 0 && kind == RQ_DIF_TRIAL) {
+#pragma unroll
+        for (int j = 0; j < kM; ++j) dp_prev[j] = su.dp[j];
+        dp_prev[kM] = su.dp_l2;
+      }
+      sm.template step<true>(sums, sums[kSums]);
+    }
     __syncthreads();
   }
 
@@ -255,6 +275,7 @@ __global__ __launch_bounds__(kWave, (METHOD == 0 ? 4 : 2)) void batch_fit_rows_k
   __shared__ Machine sm[kRowsPerWave];
   __shared__ PassUniforms<MODEL> su[kRowsPerWave];
   __shared__ int s_fit[kRowsPerWave];
+  __shared__ double s_dp[kRowsPerWave][kM + 1];  // dif: Dp and ||Dp||^2 of the row's last trial
 
   const int lane = threadIdx.x;
   const int row = lane / kRowLanes;
@@ -311,7 +332,7 @@ __global__ __launch_bounds__(kWave, (METHOD == 0 ? 4 : 2)) void batch_fit_rows_k
       const double *p0 = ctx.p + (size_t)fit * kM;
       const double *opts = ctx.has_opts ? ctx.opts : nullptr;
       if constexpr (METHOD == 0)
-        m.start(p0, n, ctx.itmax, opts, 0, /*speculative=*/0);
+        m.start(p0, n, ctx.itmax, opts, 0, /*speculative=*/1);
       else
         m.start(p0, n, ctx.has_lb ? ctx.lb : nullptr, ctx.has_ub ? ctx.ub : nullptr, nullptr, ctx.itmax, opts, 0);
     }
@@ -319,13 +340,31 @@ __global__ __launch_bounds__(kWave, (METHOD == 0 ? 4 : 2)) void batch_fit_rows_k
 
     // ---- the fit: passes until this row's machine is done (rows are in different passes: divergent switch) --
     bool busy = run;
+    int cur_sel_hx = 0, cur_sel_j = 0;  // dif, speculative protocol: what this lane's hx / Jacobian row currently reflect
     while (__any(busy)) {
       if (busy && leader) {
-        if (m.h.req.kind != RQ_DONE) su[row].build(m.h.req);
+        if (m.h.req.kind != RQ_DONE) su[row].build(m.h.req, /*need_base=*/METHOD != 0);
       }
       __syncthreads();
       const int kind = busy ? m.h.req.kind : RQ_DONE;
       if (kind == RQ_DONE) busy = false;
+      if constexpr (METHOD == 0) {
+        if (busy) {  // commit what the machine decided about the previous trial (see batch_fit_kernel)
+          if (m.h.req.sel_j != cur_sel_j) {
+            const double dpp[kM] = {s_dp[row][0], s_dp[row][1], s_dp[row][2]};
+            double jn[kM];
+            broyden_row(jac, wrk, hx, dpp, s_dp[row][kM], jn);
+            jac[0] = jn[0];
+            jac[1] = jn[1];
+            jac[2] = jn[2];
+            cur_sel_j = m.h.req.sel_j;
+          }
+          if (m.h.req.sel_hx != cur_sel_hx) {
+            hx = wrk;
+            cur_sel_hx = m.h.req.sel_hx;
+          }
+        }
+      }
       double acc[kSums];
 #pragma unroll
       for (int k = 0; k < kSums; ++k) acc[k] = 0.0;
@@ -372,25 +411,19 @@ __global__ __launch_bounds__(kWave, (METHOD == 0 ? 4 : 2)) void batch_fit_rows_k
           ns = SumLayout<kM>::DIF_JAC;
           break;
         }
-        case RQ_DIF_TRIAL: {
-          wrk = model_value_q<MODEL, FAST>(u, s0, pq);
-          const double e = ok ? sx - wrk : 0.0;
-          acc[0] = e * e;
-          ns = 1;
-          break;
-        }
-        case RQ_DIF_UPDATE: {
-          const bool accepted = m.h.req.aux != 0;
+        case RQ_DIF_TRIAL: {  // speculative protocol: sums of the Broyden-updated row; the row itself is updated next pass
+          const double w = model_value_q<MODEL, FAST>(u, s0, pq);
           double jn[kM];
-          broyden_row(jac, wrk, hx, u.dp, u.dp_l2, jn);
-          double e = sx - (accepted ? wrk : hx);
-          if (!ok) e = jn[0] = jn[1] = jn[2] = 0.0;
-          jac[0] = jn[0];
-          jac[1] = jn[1];
-          jac[2] = jn[2];
-          if (accepted) hx = wrk;
-          acc_normal_eq(jn, e, acc, acc + kNL);
-          ns = SumLayout<kM>::DIF_JAC;
+          broyden_row(jac, w, hx, u.dp, u.dp_l2, jn);
+          double en = sx - w, eo = sx - hx;
+          if (!ok) en = eo = jn[0] = jn[1] = jn[2] = 0.0;
+          wrk = w;
+          acc[0] = en * en;
+          acc_normal_eq(jn, en, acc + 1, acc + 1 + kNL);
+          acc[1 + kNL + kM + 0] = jn[0] * eo;
+          acc[1 + kNL + kM + 1] = jn[1] * eo;
+          acc[1 + kNL + kM + 2] = jn[2] * eo;
+          ns = SumLayout<kM>::DIF_TRIAL;
           break;
         }
         default: break;
@@ -402,7 +435,13 @@ __global__ __launch_bounds__(kWave, (METHOD == 0 ? 4 : 2)) void batch_fit_rows_k
       for (int k = 0; k < kSums; ++k) sums[k] = row_reduce_to_last<OpSum>(acc[k]);
       sums[kSums] = row_reduce_to_last<OpMax>(mx);
       (void)ns;
-      if (busy && leader) m.step(sums, sums[kSums]);
+      if (busy && leader) {
+        if (METHOD == 0 && kind == RQ_DIF_TRIAL) {
+          for (int k = 0; k < kM; ++k) s_dp[row][k] = u.dp[k];
+          s_dp[row][kM] = u.dp_l2;
+        }
+        m.step(sums, sums[kSums]);
+      }
       __syncthreads();
     }
 
