@@ -287,10 +287,13 @@ struct DifMachine {
   struct Cold {
     FitOptions o;
     int itmax, n, want_covar, refresh;
-    int speculative;  // 1: the trial pass also produces the Broyden-updated Jacobian and its products
-                      //    (one pass per LM iteration; needs double-buffered J/hx -- streamed regime)
-                      // 0: trial pass, decision, then an update pass (per-sample state stays single-buffered in
-                      //    registers -- batched regime, where a pass is only a workgroup-wide reduction)
+    int speculative;  // 1: the trial pass also produces the products of the Broyden-updated Jacobian (one pass per LM
+                      //    iteration).  The launch chain double-buffers J in HBM and commits by flipping sel_j; the
+                      //    resident and batched kernels keep f(p+Dp) per sample and apply the adopted update at the top
+                      //    of the next pass.  Every BRDF kernel uses this protocol.
+                      // 0: trial pass, decision, then an update pass (RQ_DIF_UPDATE), the plain restatement of
+                      //    lm_core.c:742-790: the host-callback path (generic_fit.hip), where hx and J are whole
+                      //    vectors in HBM, and the host harness (tests/cpp/host_machine.cpp; bit-exact, like 1)
     double info[kInfoSz], covar[M * M];
     int ret;
   };
