@@ -261,7 +261,7 @@ def main():
     # The dominant kernel.  Resident regime (default for dlevmar_dif when the fit fits the chip): ONE launch per fit, the
     # launch performs passes_per_fit sweeps over samples it read from HBM once.  Launch chain: one launch per sweep.
     resident = head["launches_per_step"] < 1.5
-    kernel = "resident_fit_kernel<2, 0, true>" if resident else "stream_pass<2, 0, true>"
+    kernel = "resident_fit_kernel<2, 0, true, false>" if resident else "stream_pass<2, 0, true>"
     # HBM traffic per launch: measured with rocprofv3 PMC counters in separate profiling passes of this very
     # command (scripts/profile_round.sh), corrected as MI355X_MICROARCH.md prescribes; committed under profiles/
     traffic = None
@@ -274,7 +274,7 @@ def main():
     bytes_per_launch = BYTES_PER_SAMPLE_PASS[MODEL] * N_SAMPLES * sweeps_per_launch
     achieved = bytes_per_launch / (head["avg_launch_us"] * 1e-6) / 1e9
     if resident:
-        kernel_desc = ("brdf::resident_fit_kernel<2,0,true> (one launch per fit: samples + secant Jacobian resident in registers/LDS, "
+        kernel_desc = ("brdf::resident_fit_kernel<2,0,true,false> (one launch per fit: samples + secant Jacobian resident in registers/LDS, "
                        "model eval + residual + Broyden + JtJ/Jte fused per LM evaluation, in-launch all-gather between evaluations)")
         note = ("algorithmic bytes = 32 B per sample per LM evaluation (Ward: 3 planes + measurement, fp64) x 1e6 samples x the "
                 "launch's evaluations (sweeps_per_launch); avg launch = HIP-event time around each fit's launch (its 4 KB upload "
