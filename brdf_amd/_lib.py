@@ -49,6 +49,9 @@ ABI = {
     "brdf_hip_fit_capture_dev": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_int, D, D, C.c_int, D, D, D, C.c_int, D, C.c_void_p, D,
                                            C.POINTER(C.c_longlong), C.c_void_p]),
+    "brdf_hip_fit_capture_single_dev": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                  C.c_void_p, C.c_int, D, D, C.c_int, D, D, D, C.c_int, D, D, D,
+                                                  C.POINTER(C.c_longlong), C.c_void_p]),
     "brdf_hip_device_count": (C.c_int, []),
     "brdf_hip_last_error": (C.c_char_p, []),
     "brdf_hip_last_fit_launches": (C.c_longlong, []),

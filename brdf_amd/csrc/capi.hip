@@ -379,6 +379,15 @@ int brdf_hip_fit_capture_dev(int model, const unsigned char *d_images, int L, in
                          rv_mode, p0, lb, ub, itmax, opts, d_brdf_surfaces, avg, n_pixels, static_cast<hipStream_t>(stream));
 }
 
+int brdf_hip_fit_capture_single_dev(int model, const unsigned char *d_images, int L, int H, int W, const int *d_pixel_map,
+                                    const double *d_vertices, const int *d_faces, const double *d_face_normals, int nf,
+                                    const double *leds, const double *view_origin, int rv_mode, const double *p0,
+                                    const double *lb, const double *ub, int itmax, const double *opts, double *single_brdf,
+                                    double *info, long long *n_faces_used, void *stream) {
+  return capture_fit_single_run(model, d_images, L, H, W, d_pixel_map, d_vertices, d_faces, d_face_normals, nf, leds, view_origin,
+                                rv_mode, p0, lb, ub, itmax, opts, single_brdf, info, n_faces_used, static_cast<hipStream_t>(stream));
+}
+
 int brdf_hip_device_count(void) {
   int c = 0;
   if (hipGetDeviceCount(&c) != hipSuccess) return 0;

@@ -115,6 +115,52 @@ __global__ __launch_bounds__(kCT) void store_kernel(const double *p, const int *
   if (threadIdx.x < 3) block_sums[(size_t)blockIdx.x * 3 + threadIdx.x] = red[threadIdx.x][0];
 }
 
+// ---- single-BRDF variant (CalcBRDFEquation_SingleBRDF, brdfdata.cpp:1138-1186) --------------------------------
+__global__ __launch_bounds__(kCT) void face_count_kernel(const long long *last_of_face, int nf, int *block_count) {
+  __shared__ int wave_cnt[kCT / 64];
+  const int f = blockIdx.x * kCT + threadIdx.x;
+  const bool valid = f < nf && last_of_face[f] != 0;
+  const unsigned long long m = __ballot(valid);
+  if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = __popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) block_count[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+}
+
+// the faces some pixel carries, in face order, each with the x-major index of its LAST pixel
+__global__ __launch_bounds__(kCT) void face_compact_kernel(const long long *last_of_face, const long long *pixel_of, int nf,
+                                                           const long long *block_offset, int *face_list, long long *pixel_list) {
+  __shared__ int wave_cnt[kCT / 64];
+  const int f = blockIdx.x * kCT + threadIdx.x;
+  const bool valid = f < nf && last_of_face[f] != 0;
+  const unsigned long long m = __ballot(valid);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) wave_cnt[wave] = __popcll(m);
+  __syncthreads();
+  if (!valid) return;
+  long long r = block_offset[blockIdx.x] + __popcll(m & ((1ull << lane) - 1ull));
+  for (int w = 0; w < wave; ++w) r += wave_cnt[w];
+  face_list[r] = f;
+  pixel_list[r] = pixel_of[last_of_face[f] - 1];
+}
+
+// one fit over all F faces x L lights: planes[3][F*L] (face-major inside a plane, "x[i*m_numImages+j] = I(i,j)",
+// brdfdata.cpp:1016) from the per-face planes of cosines.hip, and the measurements of the three channels x3[3][F*L]
+__global__ __launch_bounds__(kCT) void single_pack_kernel(const unsigned char *images, int L, int H, int W, const long long *pixel_list,
+                                                          const double *angles_f, long long F, double *planes, double *x3) {
+  const long long n = F * L;
+  for (long long t = (long long)blockIdx.x * kCT + threadIdx.x; t < n; t += (long long)gridDim.x * kCT) {
+    const long long r = t / L;
+    const int i = (int)(t - r * L);
+    const long long g = pixel_list[r];
+    const int px = (int)(g / H), py = (int)(g % H);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) planes[k * n + t] = angles_f[(r * 3 + k) * L + i];
+    const unsigned char *pxl = images + (((size_t)i * H + (size_t)(H - 1 - py)) * W + px) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) x3[c * n + t] = pxl[c] / 255.0;
+  }
+}
+
 struct DevBuf {
   void *ptr = nullptr;
   ~DevBuf() {
@@ -221,6 +267,111 @@ int capture_fit_run(int model, const unsigned char *d_images, int L, int H, int 
     for (int k = 0; k < 3; ++k) avg[k] = t[k] / ((double)nf * 3);  // "avg_kd/(m_faces.rows()*3)", brdfdata.cpp:1224-1226
   }
   return 0;
+}
+
+
+// CalcBRDFEquation_SingleBRDF (brdfdata.cpp:1138-1186) + SolveEquation_SingleBRDF (:992-1062): ONE parameter triple per
+// colour channel, fitted to the 16 samples of EVERY face the pixel map shows (n = 16 x faces; bunny: 402,928).  The
+// reference fills phi/thetaDash/theta/I only for the faces some pixel carries and leaves the other rows of its
+// matrices uninitialised, then pairs x (face-major) with planes read through a column-major linear index (:1031): both
+// slips are not reproduced -- the fit sees exactly the carried faces, samples and measurements paired.
+int capture_fit_single_run(int model, const unsigned char *d_images, int L, int H, int W, const int *d_pixel_map,
+                           const double *d_vertices, const int *d_faces, const double *d_normals, int nf, const double *leds,
+                           const double *view, int rv_mode, const double *p0, const double *lb, const double *ub, int itmax,
+                           const double *opts, double *single_brdf, double *info, long long *n_faces_used, hipStream_t stream) {
+  if (!d_images || !d_pixel_map || !d_vertices || !d_faces || !d_normals || !leds || !view || !p0 || !single_brdf || L <= 0 ||
+      L > 64 || H <= 0 || W <= 0 || nf <= 0) {
+    set_error("brdf_hip_fit_capture_single_dev(): bad arguments");
+    return kLmError;
+  }
+  (void)hipGetLastError();
+  const long long npx = (long long)H * W;
+  const int nb = (int)((npx + kCT - 1) / kCT), fb = (nf + kCT - 1) / kCT;
+  DevBuf counts, offsets, last, fcounts, foffsets;
+  CAP_OK(counts.alloc(sizeof(int) * nb));
+  CAP_OK(offsets.alloc(sizeof(long long) * nb));
+  CAP_OK(last.alloc(sizeof(long long) * nf));
+  CAP_OK(fcounts.alloc(sizeof(int) * fb));
+  CAP_OK(foffsets.alloc(sizeof(long long) * fb));
+  CAP_OK(hipMemsetAsync(last.ptr, 0, sizeof(long long) * nf, stream));
+  hipLaunchKernelGGL(count_kernel, dim3(nb), dim3(kCT), 0, stream, d_pixel_map, H, W, nf, counts.as<int>());
+  std::vector<int> h_counts(nb);
+  CAP_OK(hipMemcpyAsync(h_counts.data(), counts.ptr, sizeof(int) * nb, hipMemcpyDeviceToHost, stream));
+  CAP_OK(hipStreamSynchronize(stream));
+  std::vector<long long> h_off(nb);
+  long long S = 0;
+  for (int b = 0; b < nb; ++b) {
+    h_off[b] = S;
+    S += h_counts[b];
+  }
+  if (n_faces_used) *n_faces_used = 0;
+  if (S == 0) {
+    set_error("brdf_hip_fit_capture_single_dev(): no pixel carries a face");
+    return kLmError;
+  }
+  CAP_OK(hipMemcpyAsync(offsets.ptr, h_off.data(), sizeof(long long) * nb, hipMemcpyHostToDevice, stream));
+  DevBuf pixel_of, face_s;
+  CAP_OK(pixel_of.alloc(sizeof(long long) * S));
+  CAP_OK(face_s.alloc(sizeof(int) * S));
+  hipLaunchKernelGGL(compact_kernel, dim3(nb), dim3(kCT), 0, stream, d_pixel_map, H, W, nf, offsets.as<long long>(),
+                     pixel_of.as<long long>(), face_s.as<int>(), last.as<long long>());
+  hipLaunchKernelGGL(face_count_kernel, dim3(fb), dim3(kCT), 0, stream, last.as<long long>(), nf, fcounts.as<int>());
+  std::vector<int> h_fc(fb);
+  CAP_OK(hipMemcpyAsync(h_fc.data(), fcounts.ptr, sizeof(int) * fb, hipMemcpyDeviceToHost, stream));
+  CAP_OK(hipStreamSynchronize(stream));
+  std::vector<long long> h_fo(fb);
+  long long F = 0;
+  for (int b = 0; b < fb; ++b) {
+    h_fo[b] = F;
+    F += h_fc[b];
+  }
+  if (n_faces_used) *n_faces_used = F;
+  const long long n = F * L;
+  if (n > 0x7fffffffLL) {
+    set_error("brdf_hip_fit_capture_single_dev(): %lld samples exceed one fit's index range", n);
+    return kLmError;
+  }
+  CAP_OK(hipMemcpyAsync(foffsets.ptr, h_fo.data(), sizeof(long long) * fb, hipMemcpyHostToDevice, stream));
+  DevBuf face_list, pixel_list, angles_f, planes, x3;
+  CAP_OK(face_list.alloc(sizeof(int) * F));
+  CAP_OK(pixel_list.alloc(sizeof(long long) * F));
+  CAP_OK(angles_f.alloc(sizeof(double) * 3 * n));
+  CAP_OK(planes.alloc(sizeof(double) * 3 * n));
+  CAP_OK(x3.alloc(sizeof(double) * 3 * n));
+  hipLaunchKernelGGL(face_compact_kernel, dim3(fb), dim3(kCT), 0, stream, last.as<long long>(), pixel_of.as<long long>(), nf,
+                     foffsets.as<long long>(), face_list.as<int>(), pixel_list.as<long long>());
+  CAP_OK(hipGetLastError());
+  if (cosines_run(d_vertices, d_faces, d_normals, face_list.as<int>(), F, leds, L, view, rv_mode, angles_f.as<double>(), stream) != 0)
+    return kLmError;
+  long long gb = (n + kCT - 1) / kCT;
+  if (gb > 256 * 64) gb = 256 * 64;
+  hipLaunchKernelGGL(single_pack_kernel, dim3((unsigned)gb), dim3(kCT), 0, stream, d_images, L, H, W, pixel_list.as<long long>(),
+                     angles_f.as<double>(), F, planes.as<double>(), x3.as<double>());
+  CAP_OK(hipGetLastError());
+  int worst = 0;
+  for (int c = 0; c < 3; ++c) {  // "do the calculation once for each color-channel", brdfdata.cpp:1161
+    StreamFitArgs a;
+    a.method = 1;  // dlevmar_bc_dif, brdfdata.cpp:1058
+    a.model = model;
+    a.d_angles = planes.as<double>();
+    a.d_x = x3.as<double>() + (size_t)c * n;
+    a.n = (int)n;
+    double p[3] = {p0[0], p0[1], p0[2]};
+    a.p = p;
+    a.lb = lb;
+    a.ub = ub;
+    a.dscl = nullptr;
+    a.itmax = itmax;
+    a.opts = opts;
+    a.info = info ? info + 10 * c : nullptr;
+    a.covar = nullptr;
+    a.stream = stream;
+    const int r = stream_fit_run(a);
+    for (int k = 0; k < 3; ++k) single_brdf[3 * c + k] = p[k];
+    if (r < 0) worst = kLmError;
+  }
+  CAP_OK(hipStreamSynchronize(stream));
+  return worst;
 }
 
 }  // namespace brdf

@@ -83,6 +83,10 @@ FitStats stream_fit_last_stats();
 bool resident_fit_try(const StreamFitArgs &a, int *ret);
 FitStats resident_fit_last_stats();
 
+int capture_fit_single_run(int model, const unsigned char *d_images, int L, int H, int W, const int *d_pixel_map,
+                           const double *d_vertices, const int *d_faces, const double *d_normals, int nf, const double *leds,
+                           const double *view, int rv_mode, const double *p0, const double *lb, const double *ub, int itmax,
+                           const double *opts, double *single_brdf, double *info, long long *n_faces_used, hipStream_t stream);
 // vectors -> cosines (cosines.hip)
 int cosines_run(const double *d_vertices, const int *d_faces, const double *d_normals, const int *d_surfels, long long S,
                 const double *leds, int L, const double *view, int rv_mode, double *d_angles, hipStream_t stream);

@@ -158,6 +158,33 @@ def fit_capture(model: int, images, pixel_map, vertices, faces, face_normals, le
     return brdf_surfaces, avg, npx.value
 
 
+def fit_capture_single(model: int, images, pixel_map, vertices, faces, face_normals, leds, view_origin, *, rv_mode: int = 0,
+                       p0=(0.0, 0.0, 0.0), lb=(0.0, 0.0, 0.0), ub=(100.0, 100.0, 100.0), itmax: int = 2000,
+                       opts=(1e-3, 1e-15, 1e-10, 1e-50, 1.0)):
+    """CalcBRDFEquation_SingleBRDF (brdfdata.cpp:1138-1186) on the device: one {kd, ks, n} per colour channel for the
+    whole object.  Defaults are the reference's call-site values (brdfdata.cpp:1002, :1046-1056).  Returns
+    (single_brdf [3,3], info [3,10], faces used)."""
+    import torch
+    images, pixel_map = images.contiguous(), pixel_map.contiguous()
+    vertices, faces, face_normals = vertices.contiguous(), faces.contiguous(), face_normals.contiguous()
+    assert images.dtype == torch.uint8 and pixel_map.dtype == torch.int32 and faces.dtype == torch.int32
+    L, H, W = int(images.shape[0]), int(images.shape[1]), int(images.shape[2])
+    nf = int(faces.shape[0])
+    la = np.ascontiguousarray(leds, dtype=np.float64).reshape(-1, 3)
+    assert la.shape[0] == L
+    va, pa, lba, uba, oa = _f64(view_origin, 3), _f64(p0, 3), _f64(lb, 3), _f64(ub, 3), _f64(opts, 5)
+    out, info = np.zeros(9), np.zeros(30)
+    nfu = C.c_longlong(0)
+    with torch.cuda.device(images.device):
+        rc = lib.brdf_hip_fit_capture_single_dev(model, images.data_ptr(), L, H, W, pixel_map.data_ptr(), vertices.data_ptr(),
+                                                 faces.data_ptr(), face_normals.data_ptr(), nf, _dptr(la), _dptr(va), rv_mode,
+                                                 _dptr(pa), _dptr(lba), _dptr(uba), itmax, _dptr(oa), _dptr(out), _dptr(info),
+                                                 C.byref(nfu), _stream_handle(torch))
+    if rc != 0:
+        raise RuntimeError(f"brdf_hip_fit_capture_single_dev failed: {last_error()}")
+    return out.reshape(3, 3), info.reshape(3, 10), nfu.value
+
+
 def host_dlevmar(method: int, model: int, angles: np.ndarray, x: np.ndarray, p0, *, lb=None, ub=None, dscl=None,
                  itmax=100, opts=None, want_covar=False) -> FitResult:
     """The drop-in call exactly as brdfdata.cpp:1058/1119 makes it: HOST arrays, a BRDFFunc-style callback

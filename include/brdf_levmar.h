@@ -176,6 +176,21 @@ int brdf_hip_fit_capture_dev(int model, const unsigned char *d_images, int L, in
                              const double *ub, int itmax, const double *opts, double *d_brdf_surfaces, double *avg,
                              long long *n_pixels, void *stream);
 
+/* Replaces CBRDFdata::CalcBRDFEquation_SingleBRDF (brdfdata.cpp:1138-1186) with SolveEquation_SingleBRDF (:992-1062): ONE
+ * {kd, ks, n} per colour channel for the whole object, fitted with dlevmar_bc_dif to the L samples of every face the pixel
+ * map shows (n = L x faces; the reference's call site passes p0 = {0,0,0}, itmax = 2000, opts = {1e-3,1e-15,1e-10,1e-50,1},
+ * bounds [0,100]).  A face's measurements are those of its LAST pixel in the reference's walk (as its I.row(face) = ...
+ * leaves them).  Arguments as brdf_hip_fit_capture_dev; single_brdf (HOST, [3 channels B,G,R][3]) receives the fits,
+ * info (HOST [3][10], or NULL) levmar's info[] per channel, n_faces_used (HOST, or NULL) the faces that entered the fit.
+ * Deviations: faces no pixel shows are left out (the reference feeds their uninitialised matrix rows to the solver) and
+ * samples are paired with their own measurements (the reference's linear indexing at :1031 mis-pairs them).
+ * Synchronises `stream`.  Returns 0, or LM_ERROR if any channel's fit failed / on bad arguments. */
+int brdf_hip_fit_capture_single_dev(int model, const unsigned char *d_images, int L, int H, int W, const int *d_pixel_map,
+                                    const double *d_vertices, const int *d_faces, const double *d_face_normals, int nf,
+                                    const double *leds, const double *view_origin, int rv_mode, const double *p0,
+                                    const double *lb, const double *ub, int itmax, const double *opts, double *single_brdf,
+                                    double *info, long long *n_faces_used, void *stream);
+
 /* ---- diagnostics ----------------------------------------------------------------------------------- */
 int brdf_hip_device_count(void);
 const char *brdf_hip_last_error(void);

@@ -115,3 +115,46 @@ long long orc_fit_capture(int model, const unsigned char *images, int L, int H, 
   for (int k = 0; k < 3; ++k) avg[k] = sum[k] / ((double)nf * 3);
   return count;
 }
+
+/* CalcBRDFEquation_SingleBRDF + SolveEquation_SingleBRDF (brdfdata.cpp:1138-1186, :992-1062) on plain arrays, with the
+ * two deviations of the product (include/brdf_levmar.h): only the faces some pixel carries enter the fit, and every
+ * sample is paired with its own measurement.  single_brdf[3][3], info[3][10] (may be NULL); returns the number of faces
+ * used, or -1 if a fit failed.  PARITY UNPINNED, like the rest of this file.  `work` = scratch supplied by the caller:
+ * (3 + 3) * L * nf doubles + nf long longs. */
+long long orc_fit_capture_single(int model, const unsigned char *images, int L, int H, int W, const int *pixel_map,
+                                 const double *vertices, const int *faces, const double *normals, int nf, const double *leds,
+                                 const double *view, int rv_mode, const double *p0, const double *lb, const double *ub, int itmax,
+                                 const double *opts, double *single_brdf, double *info, double *work, long long *last_pixel) {
+  long long F = 0;
+  int bad = 0;
+  for (int f = 0; f < nf; ++f) last_pixel[f] = -1;
+  for (int x = 0; x < W; ++x) /* the walk of :1147-1159 / :1167-1177: a later pixel of a face overwrites an earlier one */
+    for (int y = 0; y < H; ++y) {
+      const int f = pixel_map[(size_t)y * W + x];
+      if (f > -1 && f < nf) last_pixel[f] = (long long)x * H + y;
+    }
+  for (int f = 0; f < nf; ++f)
+    if (last_pixel[f] >= 0) ++F;
+  const long long n = F * L;
+  double *planes = work, *x3 = work + 3 * n;
+  double row[3 * 64];
+  long long r = 0;
+  for (int f = 0; f < nf; ++f) {
+    if (last_pixel[f] < 0) continue;
+    const int px = (int)(last_pixel[f] / H), py = (int)(last_pixel[f] % H);
+    orc_cosines(vertices, faces, normals, &f, 1, leds, L, view, rv_mode, row);
+    for (int i = 0; i < L; ++i) {
+      for (int k = 0; k < 3; ++k) planes[k * n + r * L + i] = row[k * L + i];
+      for (int c = 0; c < 3; ++c) x3[c * n + r * L + i] = images[(((size_t)i * H + (size_t)(H - 1 - py)) * W + px) * 3 + c] / 255.0;
+    }
+    ++r;
+  }
+  for (int c = 0; c < 3; ++c) {
+    double p[3] = {p0[0], p0[1], p0[2]}, inf[10];
+    if (orc_brdf_fit(1, model, planes, x3 + c * n, (int)n, p, itmax, (double *)opts, (double *)lb, (double *)ub, inf) < 0) bad = 1;
+    for (int k = 0; k < 3; ++k) single_brdf[3 * c + k] = p[k];
+    if (info)
+      for (int k = 0; k < 10; ++k) info[10 * c + k] = inf[k];
+  }
+  return bad ? -1 : F;
+}

@@ -103,3 +103,23 @@ def fit_capture(model, images, pixel_map, vertices, faces, normals, leds, view, 
                             fc.ctypes.data_as(IP), ptr(f64(normals)), nf, ptr(f64(leds)), ptr(f64(view)), rv_mode, ptr(f64(p0)),
                             ptr(f64(lb)), ptr(f64(ub)), itmax, ptr(f64(opts)), ptr(out), ptr(avg))
     return out, avg, n
+
+
+def fit_capture_single(model, images, pixel_map, vertices, faces, normals, leds, view, rv_mode=0, p0=(0.0, 0.0, 0.0),
+                       lb=(0.0, 0.0, 0.0), ub=(100.0, 100.0, 100.0), itmax=2000, opts=(1e-3, 1e-15, 1e-10, 1e-50, 1.0)):
+    """oracle/cosines_oracle.c: orc_fit_capture_single -> (single_brdf[3,3], info[3,10], faces used)"""
+    img = np.ascontiguousarray(images, dtype=np.uint8)
+    pm = np.ascontiguousarray(pixel_map, dtype=np.int32)
+    Lc, H, W = img.shape[:3]
+    fc = np.ascontiguousarray(np.asarray(faces, dtype=np.int32).reshape(-1))
+    nf = fc.size // 3
+    out, info = np.zeros(9), np.zeros(30)
+    work = np.zeros(6 * Lc * nf)
+    last = np.zeros(nf, dtype=np.int64)
+    IP = C.POINTER(C.c_int)
+    orc.orc_fit_capture_single.restype = C.c_longlong
+    F = orc.orc_fit_capture_single(model, img.ctypes.data_as(C.c_void_p), Lc, H, W, pm.ctypes.data_as(IP), ptr(f64(vertices)),
+                                   fc.ctypes.data_as(IP), ptr(f64(normals)), nf, ptr(f64(leds)), ptr(f64(view)), rv_mode,
+                                   ptr(f64(p0)), ptr(f64(lb)), ptr(f64(ub)), itmax, ptr(f64(opts)), ptr(out), ptr(info), ptr(work),
+                                   last.ctypes.data_as(C.POINTER(C.c_longlong)))
+    return out.reshape(3, 3), info.reshape(3, 10), F

@@ -211,3 +211,20 @@ def test_device_capture_loop_against_oracle(gpu):
             assert o_got <= o_ref * (1 + 1e-3) + 1e-12, (f, ch, got[f, ch], want[f, ch])
             worst = max(worst, L.rel_err(got[f, ch], want[f, ch]))
     assert np.all(np.isfinite(avg)) and np.all(np.abs(avg - avg_ref) <= 0.05 * np.abs(avg_ref) + 1e-6)
+
+
+@pytest.mark.gpu
+def test_device_single_brdf_capture_against_oracle(gpu):
+    """CalcBRDFEquation_SingleBRDF (brdfdata.cpp:1138-1186): one fit per channel over every visible face's 16 samples, with
+    the reference's own call-site settings (p0 = 0, itmax = 2000, FD step 1).  n = 16 x faces is well conditioned, so
+    the parameters themselves are compared."""
+    torch, brdf_amd, dev = gpu
+    vertices, faces, nrm, view, leds, pixel_map, images = make_capture(H=40, W=50, nf=300, seed=9)
+    want, info_ref, F_ref = L.fit_capture_single(1, images, pixel_map, vertices, faces, nrm, leds, view, rv_mode=1)
+    tv, tf, tn = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (vertices, faces, nrm))
+    got, info, F = brdf_amd.fit_capture_single(1, torch.from_numpy(images).to(dev), torch.from_numpy(pixel_map).to(dev), tv, tf, tn,
+                                                leds, view, rv_mode=1)
+    assert F == F_ref == np.unique(pixel_map[pixel_map > -1]).size
+    for ch in range(3):
+        assert L.rel_err(got[ch], want[ch]) <= 1e-5, (ch, got[ch], want[ch])
+        assert abs(info[ch, 1] - info_ref[ch, 1]) <= 1e-8 * info_ref[ch, 1]
