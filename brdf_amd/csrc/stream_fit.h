@@ -1,4 +1,6 @@
-// stream_fit.h -- "streamed" regime: ONE large fit (n ~ 1e4 .. 1e8 samples) spread over the whole chip.
+// stream_fit.h -- "streamed" regime (launch chain): ONE large fit spread over the whole chip, one launch per pass.
+// Since resident_fit.hip took over the fits that fit the chip (n <= #CUs * 4096), this is the path of larger fits
+// (n up to ~1e8), of BRDF_HIP_RESIDENT=0, and the fallback when the resident launch cannot run.
 //
 // Every LM evaluation is one kernel launch (a *pass*) on one stream; the scalar LM state machine
 // (lm_machine.h) is re-executed redundantly at the top of each launch by every workgroup from the
