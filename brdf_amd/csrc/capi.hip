@@ -154,6 +154,13 @@ int dlevmar_der(void (*func)(double *, double *, int, int, void *), void (*jacf)
               "dlevmar_dif() rather than dlevmar_der()");
     return LM_ERROR;
   }
+  if (is_registered(func) && jacf == &BRDFJac_hip) {  // a built-in model with its own analytic Jacobian: resident regime
+    double keep[8];
+    for (int i = 0; i < m && i < 8; ++i) keep[i] = p[i];
+    const int r = host_fit(2, "dlevmar_der", func, p, x, m, n, nullptr, nullptr, nullptr, itmax, opts, info, covar, adata, 1);
+    if (r != kStreamNoDevicePath) return r;
+    for (int i = 0; i < m && i < 8; ++i) p[i] = keep[i];  // too large for the chip: BRDFFunc_hip / BRDFJac_hip as plain callbacks
+  }
   return generic_fit_run(2, func, jacf, p, x, m, n, nullptr, nullptr, nullptr, itmax, opts, info, covar, adata);
 }
 
@@ -273,8 +280,8 @@ int brdf_hip_fit_dev(int method, int model, const double *d_angles, const double
                      const double *lb, const double *ub, const double *dscl, int itmax, const double *opts,
                      double *info, double *covar, void *stream) {
   StreamFitArgs a;
-  a.method = (method == BRDF_METHOD_BC_DER) ? BRDF_METHOD_BC_DIF : method;
-  a.analytic = (method == BRDF_METHOD_BC_DER) ? 1 : 0;
+  a.method = (method == BRDF_METHOD_BC_DER) ? 1 : (method == BRDF_METHOD_DER ? 2 : method);  // internal: 2 = DerMachine
+  a.analytic = (method == BRDF_METHOD_BC_DER || method == BRDF_METHOD_DER) ? 1 : 0;
   a.model = model;
   a.d_angles = d_angles;
   a.d_x = d_x;
@@ -288,7 +295,8 @@ int brdf_hip_fit_dev(int method, int model, const double *d_angles, const double
   a.info = info;
   a.covar = covar;
   a.stream = static_cast<hipStream_t>(stream);
-  return stream_fit_run(a);
+  const int r = stream_fit_run(a);
+  return r == kStreamNoDevicePath ? LM_ERROR : r;
 }
 
 int brdf_hip_fit_batch_dev(int method, int model, const double *d_angles, const double *d_x, int S, int n,

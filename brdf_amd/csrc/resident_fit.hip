@@ -73,8 +73,9 @@ struct ResidentCtx {
   int sabotage_epoch;    // test hook (BRDF_HIP_RESIDENT_SABOTAGE): the last workgroup withholds its row at this epoch; -1 = never
 };
 
+// METHOD 0 dlevmar_dif, 1 dlevmar_bc_dif / bc_der, 2 dlevmar_der (analytic Jacobian, lm_core.c:64-432)
 template <int METHOD>
-using RMachine = typename std::conditional<METHOD == 0, DifMachine<kM>, BcMachine<kM>>::type;
+using RMachine = typename std::conditional<METHOD == 0, DifMachine<kM>, typename std::conditional<METHOD == 1, BcMachine<kM>, DerMachine<kM>>::type>::type;
 
 __device__ __forceinline__ void put_value(u64 *rows, int stride, int word, int col, unsigned tag, double v) {
   const u64 bits = (u64)__double_as_longlong(v);
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
     if constexpr (METHOD == 1)
       su.build(sm.h.req, true, sm.c.analytic_jac != 0);
     else
-      su.build(sm.h.req);
+      su.build(sm.h.req, true, METHOD == 2);
   }
   __syncthreads();
 
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
         if constexpr (METHOD == 1)
           su.build(sm.h.req, /*need_base=*/false, sm.c.analytic_jac != 0);
         else
-          su.build(sm.h.req, /*need_base=*/false);
+          su.build(sm.h.req, /*need_base=*/false, METHOD == 2);
       }
       __syncthreads();  // B: the next request and its uniforms are in LDS
       RSTAMP(4);
@@ -490,7 +491,7 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
     double mx = 0.0;
     switch (kind) {
     case RQ_EVAL:  // (the four kinds only dlevmar_bc_dif / bc_der issue are compiled into those kernels only)
-      if constexpr (METHOD == 1) {
+      if constexpr (METHOD != 0) {
 #pragma unroll
       for (int k = 0; k < kRSpt; ++k) if (k < nk) {
         const double f = model_value<MODEL, FAST>(u, s0[k], pq[k]);
@@ -502,7 +503,7 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
       }
       break;
     case RQ_SCALED:
-      if constexpr (METHOD == 1) {
+      if constexpr (METHOD != 0) {
 #pragma unroll
       for (int k = 0; k < kRSpt; ++k) if (k < nk) {
         const double f = model_value<MODEL, FAST>(u, s0[k], pq[k]);
@@ -513,7 +514,7 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
       }
       break;
     case RQ_EVAL_MULTI:
-      if constexpr (METHOD == 1) {
+      if constexpr (METHOD != 0) {
 #pragma unroll
       for (int k = 0; k < kRSpt; ++k) if (k < nk) {
 #pragma unroll
@@ -527,7 +528,7 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
       }
       break;
     case RQ_JAC:
-      if constexpr (METHOD == 1) {
+      if constexpr (METHOD != 0) {
 #pragma unroll
       for (int k = 0; k < kRSpt; ++k) if (k < nk) {
         double f0 = 0.0, j[kM];
@@ -663,6 +664,12 @@ int resident_attempt(const StreamFitArgs &a, RWorkspace &ws, bool *retry_exact, 
     m.start(a.p, a.n, a.itmax, a.opts, a.covar != nullptr, /*speculative=*/1);
     if (m.h.req.kind == RQ_DONE) {
       set_error("dlevmar_dif(): cannot solve a problem with fewer measurements [%d] than unknowns [%d]", a.n, kM);
+      return kLmError;
+    }
+  } else if constexpr (METHOD == 2) {
+    m.start(a.p, a.n, a.itmax, a.opts, a.covar != nullptr);
+    if (m.h.req.kind == RQ_DONE) {
+      set_error("dlevmar_der(): cannot solve a problem with fewer measurements [%d] than unknowns [%d]", a.n, kM);
       return kLmError;
     }
   } else {
@@ -808,13 +815,16 @@ bool resident_fit_try(const StreamFitArgs &a, int *ret) {
   if ((long long)a.n > (long long)ws.cus * kRTile || ws.cus > kRowStride) return false;  // does not fit the chip: launch chain
   bool unavailable = false;
   int r;
-  switch (a.model * 2 + a.method) {
+  switch (a.model * 3 + a.method) {
   case 0: r = resident_run_mm<0, 0>(a, ws, &unavailable); break;
   case 1: r = resident_run_mm<0, 1>(a, ws, &unavailable); break;
-  case 2: r = resident_run_mm<1, 0>(a, ws, &unavailable); break;
-  case 3: r = resident_run_mm<1, 1>(a, ws, &unavailable); break;
-  case 4: r = resident_run_mm<2, 0>(a, ws, &unavailable); break;
-  default: r = resident_run_mm<2, 1>(a, ws, &unavailable); break;
+  case 2: r = resident_run_mm<0, 2>(a, ws, &unavailable); break;
+  case 3: r = resident_run_mm<1, 0>(a, ws, &unavailable); break;
+  case 4: r = resident_run_mm<1, 1>(a, ws, &unavailable); break;
+  case 5: r = resident_run_mm<1, 2>(a, ws, &unavailable); break;
+  case 6: r = resident_run_mm<2, 0>(a, ws, &unavailable); break;
+  case 7: r = resident_run_mm<2, 1>(a, ws, &unavailable); break;
+  default: r = resident_run_mm<2, 2>(a, ws, &unavailable); break;
   }
   if (unavailable) {
     static bool warned = false;

@@ -71,6 +71,7 @@ struct StreamFitArgs {
   double *info, *covar;
   hipStream_t stream;
 };
+constexpr int kStreamNoDevicePath = -1000;  // stream_fit_run: method 2 (dlevmar_der) could not run in the resident regime
 int stream_fit_run(const StreamFitArgs &a);
 
 struct FitStats {

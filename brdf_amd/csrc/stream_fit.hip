@@ -647,8 +647,8 @@ int stream_fit_run(const StreamFitArgs &a) {
     set_error("unknown BRDF model %d (0 Phong, 1 Blinn-Phong, 2 Ward)", a.model);
     return kLmError;
   }
-  if (a.method != 0 && a.method != 1) {
-    set_error("unknown method %d (0 dlevmar_dif, 1 dlevmar_bc_dif)", a.method);
+  if (a.method != 0 && a.method != 1 && a.method != 2) {
+    set_error("unknown method %d (0 dlevmar_dif, 1 dlevmar_bc_dif / bc_der, 2 dlevmar_der)", a.method);
     return kLmError;
   }
   if (!a.p || !a.d_angles || a.n <= 0) {
@@ -678,6 +678,10 @@ int stream_fit_run(const StreamFitArgs &a) {
     }
     for (int i = 0; i < kM; ++i) a.p[i] = p_keep[i];
     g_last_was_resident = false;
+  }
+  if (a.method == 2) {  // dlevmar_der has no launch-chain kernels: the caller (capi.hip) goes through the host-callback path
+    set_error("dlevmar_der on the device needs the resident regime (n <= #CUs * 4096, GPU not shared)");
+    return kStreamNoDevicePath;
   }
   bool retry = false;
   int ret = stream_fit_attempt(a, brdf_fast_path_enabled(), &retry);

@@ -9,7 +9,7 @@ import numpy as np
 from ._lib import D, ExtraData, last_error, lib
 
 MODEL_PHONG, MODEL_BLINN_PHONG, MODEL_WARD = 0, 1, 2
-METHOD_DIF, METHOD_BC_DIF, METHOD_BC_DER = 0, 1, 2  # 2: dlevmar_bc_der with the model's analytic Jacobian
+METHOD_DIF, METHOD_BC_DIF, METHOD_BC_DER, METHOD_DER = 0, 1, 2, 3  # 2 / 3: dlevmar_bc_der / dlevmar_der with the analytic Jacobian
 
 
 @dataclass
@@ -201,6 +201,9 @@ def host_dlevmar(method: int, model: int, angles: np.ndarray, x: np.ndarray, p0,
     if method == METHOD_DIF:
         ret = lib.dlevmar_dif(func, _dptr(p), _dptr(x), 3, n, itmax, _dptr(op_a), _dptr(info), None, _dptr(covar),
                               C.byref(ed))
+    elif method == METHOD_DER:  # dlevmar_der(BRDFFunc_hip, BRDFJac_hip, ...)
+        ret = lib.dlevmar_der(func, C.cast(lib.BRDFJac_hip, C.c_void_p), _dptr(p), _dptr(x), 3, n, itmax, _dptr(op_a), _dptr(info),
+                              None, _dptr(covar), C.byref(ed))
     elif method == METHOD_BC_DER:  # dlevmar_bc_der(BRDFFunc_hip, BRDFJac_hip, ...): the analytic Jacobian, all on the device
         ret = lib.dlevmar_bc_der(func, C.cast(lib.BRDFJac_hip, C.c_void_p), _dptr(p), _dptr(x), 3, n, _dptr(lb_a), _dptr(ub_a),
                                  _dptr(ds_a), itmax, _dptr(op_a), _dptr(info), None, _dptr(covar), C.byref(ed))

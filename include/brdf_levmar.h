@@ -38,7 +38,8 @@ struct brdf_extra_data {
 
 enum { BRDF_MODEL_PHONG = 0, BRDF_MODEL_BLINN_PHONG = 1, BRDF_MODEL_WARD = 2 };
 enum { BRDF_METHOD_DIF = 0, BRDF_METHOD_BC_DIF = 1,
-       BRDF_METHOD_BC_DER = 2 /* brdf_hip_fit_dev only: dlevmar_bc_der with the model's analytic Jacobian */ };
+       BRDF_METHOD_BC_DER = 2, /* brdf_hip_fit_dev only: dlevmar_bc_der with the model's analytic Jacobian */
+       BRDF_METHOD_DER = 3     /* brdf_hip_fit_dev only: dlevmar_der with it (n <= #CUs * 4096: resident regime only) */ };
 
 /* ---- drop-in solver entry points ----------------------------------------------------------------- */
 

@@ -1093,6 +1093,8 @@ int orc_brdf_fit(int method, int model, double *angles, double *x, int n, double
   d.angles = angles;
   d.modelInfo = model;
   if (method == 0) return orc_dlevmar_dif(orc_brdf_func, p, x, 3, n, itmax, opts, info, NULL, NULL, &d);
+  if (method == 3) /* dlevmar_der with the analytic Jacobian */
+    return orc_dlevmar_der(orc_brdf_func, orc_brdf_jac, p, x, 3, n, itmax, opts, info, NULL, NULL, &d);
   if (method == 2) /* dlevmar_bc_der with the analytic Jacobian */
     return orc_dlevmar_bc_der(orc_brdf_func, orc_brdf_jac, p, x, 3, n, lb, ub, NULL, itmax, opts, info, NULL, NULL, &d);
   return orc_dlevmar_bc_dif(orc_brdf_func, p, x, 3, n, lb, ub, NULL, itmax, opts, info, NULL, NULL, &d);

@@ -66,7 +66,7 @@ int orc_dlevmar_bc_dif(orc_func_t f, double *p, double *x, int m, int n, double 
                        double *covar, void *adata);
 
 /* convenience for ctypes callers: one BRDF fit with the reference call-site conventions
- * (brdfdata.cpp:1085-1119).  method 0 = dlevmar_dif, 1 = dlevmar_bc_dif, 2 = dlevmar_bc_der with orc_brdf_jac.
+ * (brdfdata.cpp:1085-1119).  method 0 = dlevmar_dif, 1 = dlevmar_bc_dif, 2 = dlevmar_bc_der, 3 = dlevmar_der (both with orc_brdf_jac).
  * Returns the solver's return. */
 int orc_brdf_fit(int method, int model, double *angles, double *x, int n, double *p, int itmax,
                  double *opts, double *lb, double *ub, double *info);

@@ -18,6 +18,8 @@ int ref_brdf_fit(int method, int model, double *angles, double *x, int n, double
   d.modelInfo = model;
   if (method == 0)
     return dlevmar_dif(orc_brdf_func, p, x, 3, n, itmax, opts, info, 0, 0, &d);
+  if (method == 3) /* the reference's dlevmar_der driven by our analytic Jacobian */
+    return dlevmar_der(orc_brdf_func, orc_brdf_jac, p, x, 3, n, itmax, opts, info, 0, 0, &d);
   if (method == 2) /* the reference's dlevmar_bc_der driven by our analytic Jacobian */
     return dlevmar_bc_der(orc_brdf_func, orc_brdf_jac, p, x, 3, n, lb, ub, 0, itmax, opts, info, 0, 0, &d);
   return dlevmar_bc_dif(orc_brdf_func, p, x, 3, n, lb, ub, 0, itmax, opts, info, 0, 0, &d);

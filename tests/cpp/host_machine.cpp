@@ -176,6 +176,22 @@ int fit(int method, double *angles, double *x, int n, double *p, int itmax, doub
     if (passes) *passes = np;
     return m.c.ret;
   }
+  if (method == 3) {  // dlevmar_der with the analytic Jacobian
+    HostPasses<MODEL, FAST> hp(angles, x, n, 1);  // J^T J blocking rule of lm_core.c:221 (n*m < 1024), as in lmbc_core.c
+    hp.analytic = true;
+    DerMachine<3> m;
+    m.start(p, n, itmax, opts, covar != nullptr);
+    while (m.h.req.kind != RQ_DONE) {
+      hp.run(m.h.req, s, mx);
+      ++np;
+      m.step(s, mx);
+    }
+    for (int i = 0; i < 3; ++i) p[i] = m.h.p[i];
+    if (info) for (int i = 0; i < 10; ++i) info[i] = m.c.info[i];
+    if (covar) for (int i = 0; i < 9; ++i) covar[i] = m.c.covar[i];
+    if (passes) *passes = np;
+    return m.c.ret;
+  }
   HostPasses<MODEL, FAST> hp(angles, x, n, 1);
   hp.analytic = (method == 2);
   BcMachine<3> m;

@@ -31,7 +31,7 @@ def main():
     for n in (16, 64, 341, 342, 1000, 10000):
         for model in (0, 1, 2):
             angles, x, _ = synth.make_single(model, n)
-            for method in (0, 1, 2):  # 2 = the reference's dlevmar_bc_der driven by the analytic Jacobian (f3)
+            for method in (0, 1, 2, 3):  # 2 / 3 = the reference's dlevmar_bc_der / dlevmar_der driven by the analytic Jacobian (f3)
                 r, p, info = L.brdf_fit("ref", method, model, angles, x, synth.P0[model], synth.ITMAX, synth.OPTS,
                                         synth.LB, synth.UB)
                 fits.append({"n": n, "model": model, "method": method, "ret": int(r), "p": [float.hex(v) for v in p],

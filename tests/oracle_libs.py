@@ -41,8 +41,9 @@ def brdf_fit(which: str, method: int, model: int, angles, x, p0, itmax=100, opts
         r = ref.ref_brdf_fit(method, model, ptr(a), ptr(xx), n, ptr(p), itmax, ptr(o), ptr(l), ptr(u), ptr(info))
     elif which in ("hm", "hm_fast"):
         fn = hm.hm_brdf_fit if which == "hm" else hm.hm_brdf_fit_fast
-        r = fn(method, model, ptr(a), ptr(xx), n, ptr(p), itmax, ptr(o), ptr(l) if method else None,
-               ptr(u) if method else None, None, ptr(info), None, None)
+        bc = method in (1, 2)
+        r = fn(method, model, ptr(a), ptr(xx), n, ptr(p), itmax, ptr(o), ptr(l) if bc else None,
+               ptr(u) if bc else None, None, ptr(info), None, None)
     else:
         raise ValueError(which)
     return r, p, info

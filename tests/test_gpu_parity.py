@@ -376,6 +376,25 @@ def test_bc_der_with_the_analytic_device_jacobian(gpu, model, monkeypatch):
         assert err_ref.min() > 0.5 and np.max(np.abs(err - err_ref)) <= 0.1
 
 
+@pytest.mark.parametrize("model", [0, 1, 2])
+def test_der_with_the_analytic_device_jacobian(gpu, model, monkeypatch):
+    """dlevmar_der (lm_core.c:64-432) with BRDFJac_hip: the resident regime runs it on the device (DerMachine); the
+    drop-in falls back to the host-callback path when the resident regime is not available"""
+    torch, brdf_amd, dev = gpu
+    for n in (1000, 100003):
+        angles, x, _ = synth.make_single(model, n)
+        _, p_ref, info_ref = L.brdf_fit("orc", 3, model, angles, x, synth.P0[model], synth.ITMAX, synth.OPTS)
+        res = _dev_fit(gpu, 3, model, angles, x)
+        _check(res, p_ref, info_ref)
+        assert brdf_amd.last_fit_stats()["launches"] == 1
+        res = brdf_amd.host_dlevmar(3, model, angles, x, synth.P0[model], itmax=synth.ITMAX, opts=synth.OPTS)
+        _check(res, p_ref, info_ref)
+    monkeypatch.setenv("BRDF_HIP_RESIDENT", "0")  # no resident regime: BRDFFunc_hip / BRDFJac_hip become plain host callbacks
+    angles, x, _ = synth.make_single(model, 1000)
+    _, p_ref, info_ref = L.brdf_fit("orc", 3, model, angles, x, synth.P0[model], synth.ITMAX, synth.OPTS)
+    _check(brdf_amd.host_dlevmar(3, model, angles, x, synth.P0[model], itmax=synth.ITMAX, opts=synth.OPTS), p_ref, info_ref)
+
+
 def test_diagonal_scaling_and_nan_input(gpu):
     """dscl (lmbc_core.c:536-540, :555-569) and the stop-reason-7 path (non-finite function values ->
     LM_ERROR, lm_core.c:562, :749; lmbc_core.c:534)"""

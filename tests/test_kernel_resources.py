@@ -31,5 +31,5 @@ def test_resident_kernels_do_not_spill_their_samples(tmp_path):
         assert l <= 160 * 1024, (nme, l)  # one workgroup per CU must fit the CU's LDS
         if m.group(3) == "1":  # FAST (prepared-sample) kernels: the ones every fit with positive cosines takes
             worst[nme] = sp
-    assert len(worst) == 12  # 3 models x 2 entry points x {single fit, batched}
+    assert len(worst) == 15  # 3 models x (dif, bc_dif/bc_der: single fit + batched; der: single fit)
     assert max(worst.values()) <= 8, worst

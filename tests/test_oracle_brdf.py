@@ -20,7 +20,7 @@ def _hex(v):
 
 
 def _id(f):
-    return f"n{f['n']}-model{f['model']}-{('dif', 'bc_dif', 'bc_der')[f['method']]}"
+    return f"n{f['n']}-model{f['model']}-{('dif', 'bc_dif', 'bc_der', 'der')[f['method']]}"
 
 
 @pytest.mark.parametrize("fit", FITS, ids=_id)
