@@ -84,3 +84,16 @@ def test_covariance_helpers():
     covar = np.array([float.fromhex(s) for s in next(k for k in gold if k["problem"] == 4)["covar"]])
     assert lib.dlevmar_stddev(covar.ctypes.data_as(D), 3, 0) == np.sqrt(covar[0])
     assert lib.dlevmar_corcoef(covar.ctypes.data_as(D), 3, 0, 1) == covar[1] / np.sqrt(covar[0] * covar[4])
+
+
+def test_integration_guide_only_names_declared_entry_points():
+    """INTEGRATION.md is the maintainer's recipe: every library symbol it mentions must be declared in the header"""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "brdf_levmar.h")).read()
+    guide = open(os.path.join(root, "INTEGRATION.md")).read()
+    names = set(re.findall(r"\b(brdf_hip_[a-z_]+|dlevmar_[a-z_]+|BRDF[A-Za-z]+_hip)\b", guide))
+    names -= {"brdf_hip"}  # "-lbrdf_hip"
+    assert len(names) >= 10
+    missing = sorted(n for n in names if not re.search(r"\b" + re.escape(n) + r"\s*\(", header))
+    assert not missing, missing
