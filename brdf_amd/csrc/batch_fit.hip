@@ -566,9 +566,17 @@ RowsFn rows_kernel(int model, int method, bool fast) {
   return table[fast ? 1 : 0][model][method];
 }
 
-bool rows_path_enabled() {  // BRDF_HIP_ROWS=0 selects the one-wave-per-fit kernel for n <= 16 as well
+// n <= 16: four fits per wavefront or one wave per fit?  Measured (2^18 fits of 16 samples, Blinn-Phong / Ward):
+//   dlevmar_dif     rows kernel 1.95e7 / 1.46e7 fits/s, wave per fit 8.2e6 / 6.3e6   -> rows kernel
+//   dlevmar_bc_dif  rows kernel 2.99e6 / 1.27e6,        wave per fit 3.95e6 / 2.09e6 -> wave per fit: bc_dif's long,
+//                   divergent steps (line search, projected gradient) serialise over the four row leaders, and the
+//                   wave-per-fit kernel evaluates up to 8 projected-gradient candidates per pass
+// BRDF_HIP_ROWS=0: never the rows kernel; BRDF_HIP_ROWS=1: the rows kernel for both entry points.
+bool rows_path_enabled(int method) {
   const char *e = getenv("BRDF_HIP_ROWS");
-  return !(e && e[0] == '0');
+  if (e && e[0] == '0') return false;
+  if (e && e[0] == '1') return true;
+  return method == 0;
 }
 
 struct QueueBuf {
@@ -677,7 +685,7 @@ int batch_fit_enqueue(const BatchFitArgs &a) {
       }
 
   const bool fast = brdf_fast_path_enabled() || a.model == MODEL_WARD;
-  if (a.n <= kRowLanes && rows_path_enabled()) return rows_enqueue(a, c, fast);
+  if (a.n <= kRowLanes && rows_path_enabled(a.method)) return rows_enqueue(a, c, fast);
   if (g.threads == 512 && big_path_enabled()) {  // 1024 < n <= 4096: control wave + seven sample waves per fit (resident_fit.hip)
     c.multi = pg_candidates();
     if (!fast) HIP_OK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(fb.ptr), kNeedsExact, (size_t)a.S, a.stream));

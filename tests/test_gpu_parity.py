@@ -255,6 +255,25 @@ def test_batch_fit_vs_oracle(gpu, method, model, n):
     assert worst <= P_TOL
 
 
+@pytest.mark.parametrize("rows", ["0", "1"])
+def test_both_kernels_for_sixteen_sample_fits(gpu, monkeypatch, rows):
+    """n <= 16 has two kernels (batch_fit.hip): four fits per wavefront (default for dlevmar_dif) and one wave per fit
+    (default for dlevmar_bc_dif); BRDF_HIP_ROWS=0 / 1 forces one of them for both entry points.  Objective parity
+    against the oracle for each combination."""
+    monkeypatch.setenv("BRDF_HIP_ROWS", rows)
+    model, n, S = 1, 16, 40
+    angles, x, _ = synth.make_surfels(model, n, first=7, count=S)
+    p0 = np.tile(np.array(synth.P0[model]), (S, 1))
+    for method in (0, 1):
+        p, info, ret = _batch(gpu, method, model, angles, x, p0)
+        for s in range(S):
+            r, _, info_ref = L.brdf_fit("orc", method, model, angles[s], x[s], synth.P0[model], synth.ITMAX, synth.OPTS,
+                                        synth.LB, synth.UB)
+            assert ret[s] >= 0 or r < 0
+            if r >= 0 and ret[s] >= 0:
+                assert info[s, 1] <= info_ref[1] * (1 + 1e-3) + 1e-30
+
+
 def test_batch_results_do_not_depend_on_batch_composition(gpu):
     """fits are independent: fitting surfels [0,64) at once or in two halves gives bit-identical outputs
     (this is what makes sharding across GPUs exact)"""
