@@ -58,6 +58,37 @@ def cpu_baseline(method, angles, x, p0, opts, lb, ub, itmax, budget_s=12.0):
                       f"({secs:.1f} s of CPU time, gcc -O2)"}, p, info
 
 
+def cpu_baseline_batched(method, n, count, budget_s=10.0):
+    """the reference's CPU levmar (oracle/_ref, or our restatement) on the first `count` surfels of the multi-surfel
+    workload, one after the other on ONE host core, as the reference's pixel loop does (brdfdata.cpp:1195-1220)"""
+    from brdf_amd import synth
+    ref_path = os.path.join(ROOT, "oracle", "_ref", "liblevmar_ref.so")
+    if os.path.exists(ref_path):
+        lib, fn, kind = C.CDLL(ref_path), "ref_brdf_fit", "reference"
+    else:
+        lib, fn, kind = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so")), "orc_brdf_fit", "port"
+    D = C.POINTER(C.c_double)
+    angles, x, _ = synth.make_surfels(MODEL, n, first=0, count=count)
+    lb, ub = synth.bounds(MODEL)
+    o, l, u = (np.array(v, dtype=np.float64) for v in (synth.OPTS, lb, ub))
+    fits, evals, secs = 0, 0.0, 0.0
+    for s_ in range(count):
+        p = np.array(synth.P0[MODEL], dtype=np.float64)
+        info = np.zeros(10)
+        a = np.ascontiguousarray(angles[s_].reshape(-1))
+        xs = np.ascontiguousarray(x[s_])
+        t0 = time.perf_counter()
+        getattr(lib, fn)(method, MODEL, a.ctypes.data_as(D), xs.ctypes.data_as(D), n, p.ctypes.data_as(D), synth.ITMAX,
+                         o.ctypes.data_as(D), l.ctypes.data_as(D), u.ctypes.data_as(D), info.ctypes.data_as(D))
+        secs += time.perf_counter() - t0
+        evals += info[7] * n
+        fits += 1
+        if secs > budget_s:
+            break
+    return {"value": evals / secs, "unit": "residual-evals/s", "cores": 1, "kind": kind, "fits_per_s": fits / secs,
+            "sample": f"the first {fits} surfels of the workload, one fit after the other ({secs:.1f} s of CPU time, gcc -O2)"}
+
+
 def main_batched(args):
     """BASELINE.json configs[3] (65,536 surfels x 4,096 samples) / configs[4] (2^20 x 256), Ward, batched regime:
     every rank generates (on the device) and fits only its own contiguous surfel range; ONE RCCL gather of the fitted
@@ -129,6 +160,8 @@ def main_batched(args):
                              "note": "batched regime: the samples are read from HBM once per fit (min_traffic = 32 B x n x S + 104 B per fit) "
                                      "and the LM iterations run out of registers; the kernel is bound by fp64 VALU issue and the serial LM step, "
                                      "not by HBM (DESIGN.md section 4)"}}
+        if not args.no_cpu and world == 1:
+            line["cpu_baseline"] = cpu_baseline_batched(method, n, 2048 if n > 1024 else 32768)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
