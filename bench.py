@@ -161,7 +161,7 @@ def main_batched(args):
                                      "and the LM iterations run out of registers; the kernel is bound by fp64 VALU issue and the serial LM step, "
                                      "not by HBM (DESIGN.md section 4)"}}
         if not args.no_cpu and world == 1:
-            line["cpu_baseline"] = cpu_baseline_batched(method, n, 2048 if n > 1024 else 32768)
+            line["cpu_baseline"] = cpu_baseline_batched(method, n, 768 if n > 1024 else 4096)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
