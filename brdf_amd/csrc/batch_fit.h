@@ -34,6 +34,7 @@ struct BatchCtx {
   int S, n, itmax;
   int has_opts, has_lb, has_ub;
   int multi;  // bc_dif: projected-gradient candidates per sweep (workgroup/wave-per-fit kernels)
+  int lane_quorum, lane_maxwait;  // lane_fit.hip: lanes waiting for / rounds between two heavy rounds
   double opts[5], lb[kM], ub[kM];
 };
 
@@ -41,6 +42,10 @@ struct BatchCtx {
 // fast = false: only the fits whose flag is kNeedsExact are fitted (exact model path)
 int resident_batch_enqueue(int model, int method, bool fast, const BatchCtx &c, hipStream_t stream);
 
+
+// n <= kLaneMaxN, dlevmar_bc_dif: one lane per fit (lane_fit.hip).  queue: two zeroed ints
+constexpr int kLaneMaxN = 16;
+int lane_fit_enqueue(int model, bool fast, const BatchCtx &c, int *queue, hipStream_t stream);
 
 int synth_enqueue(int model, unsigned long long seed, long long first, int count, int n, const double *d_truth,
                   double *d_angles, double *d_x, hipStream_t stream);

@@ -533,12 +533,18 @@ BatchFn kernel_for(const Geometry &g, int model, int method, bool fast) {
   return pick<512, 8>(model, method, fast);
 }
 
-struct FlagBuf {
+// Per-thread scratch of a batch call: flags[S] (kNeedsExact marks, read by the second launch) and two work-queue
+// counters.  A call is asynchronous on the caller's stream, so the NEXT call of this thread -- possibly on another
+// stream -- must not touch the scratch before the previous call's launches have finished with it: every call waits
+// (device-side, hipStreamWaitEvent) on the event the previous call recorded behind its last launch.
+struct BatchScratch {
   int *ptr = nullptr;
-  size_t cap = 0;
+  size_t cap = 0;  // ints, without the two queue words
   int device = -1;
+  hipEvent_t last_use = nullptr;
+  bool in_use = false;
 };
-thread_local FlagBuf g_flags;
+thread_local BatchScratch g_scratch;
 
 }  // namespace
 
@@ -579,40 +585,34 @@ bool rows_path_enabled(int method) {
   return method == 0;
 }
 
-struct QueueBuf {
-  int *ptr = nullptr;
-  int device = -1;
-};
-thread_local QueueBuf g_queue;
-
 // four fits per wavefront, rows pull work from a queue: a few waves per SIMD on every CU are enough
-int rows_enqueue(const BatchFitArgs &a, const BatchCtx &c, bool fast) {
-  int dev = 0;
+int rows_enqueue(const BatchFitArgs &a, const BatchCtx &c, bool fast, int *queue) {
+  int dev = 0, cus = 0;
   HIP_OK(hipGetDevice(&dev));
-  QueueBuf &q = g_queue;
-  if (q.device != dev || !q.ptr) {
-    HIP_OK(hipMalloc(&q.ptr, 2 * sizeof(int)));
-    q.device = dev;
-  }
-  hipDeviceProp_t prop;
-  HIP_OK(hipGetDeviceProperties(&prop, dev));
-  long long waves = (long long)prop.multiProcessorCount * 16;  // 4 waves per SIMD
+  HIP_OK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  long long waves = (long long)cus * 16;  // 4 waves per SIMD
   const long long need = ((long long)a.S + kRowsPerWave - 1) / kRowsPerWave;
   if (waves > need) waves = need;
-  HIP_OK(hipMemsetAsync(q.ptr, 0, 2 * sizeof(int), a.stream));
   if (fast) {
-    hipLaunchKernelGGL(rows_kernel(a.model, a.method, true), dim3((unsigned)waves), dim3(kWave), 0, a.stream, c, q.ptr);
+    hipLaunchKernelGGL(rows_kernel(a.model, a.method, true), dim3((unsigned)waves), dim3(kWave), 0, a.stream, c, queue);
     HIP_OK(hipGetLastError());
     if (a.model != MODEL_WARD) {
-      hipLaunchKernelGGL(rows_kernel(a.model, a.method, false), dim3((unsigned)waves), dim3(kWave), 0, a.stream, c, q.ptr + 1);
+      hipLaunchKernelGGL(rows_kernel(a.model, a.method, false), dim3((unsigned)waves), dim3(kWave), 0, a.stream, c, queue + 1);
       HIP_OK(hipGetLastError());
     }
   } else {
     HIP_OK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c.flags), kNeedsExact, (size_t)a.S, a.stream));
-    hipLaunchKernelGGL(rows_kernel(a.model, a.method, false), dim3((unsigned)waves), dim3(kWave), 0, a.stream, c, q.ptr);
+    hipLaunchKernelGGL(rows_kernel(a.model, a.method, false), dim3((unsigned)waves), dim3(kWave), 0, a.stream, c, queue);
     HIP_OK(hipGetLastError());
   }
   return 0;
+}
+
+// n <= 16, dlevmar_bc_dif: one lane per fit (lane_fit.hip).  Measured (2^20 fits of 16 samples): see DESIGN.md section 6.
+// BRDF_HIP_LANE=0: the wave-per-fit / rows kernels of this file instead.
+bool lane_path_enabled() {
+  const char *e = getenv("BRDF_HIP_LANE");
+  return !(e && e[0] == '0');
 }
 
 }  // namespace
@@ -622,6 +622,57 @@ static bool big_path_enabled() {
   const char *e = getenv("BRDF_HIP_BATCH_BIG");
   return !(e && e[0] == '0');
 }
+
+namespace {
+int batch_fit_launches(const BatchFitArgs &a, const Geometry &g, int *flags, int *queue) {
+  BatchCtx c;
+  memset(&c, 0, sizeof c);
+  c.angles = a.d_angles;
+  c.x = a.d_x;
+  c.p = a.d_p;
+  c.info = a.d_info;
+  c.ret = a.d_ret;
+  c.flags = flags;
+  c.S = a.S;
+  c.n = a.n;
+  c.itmax = a.itmax;
+  c.has_opts = a.opts != nullptr;
+  c.has_lb = a.lb != nullptr;
+  c.has_ub = a.ub != nullptr;
+  // projected-gradient candidates per sweep: pays where the LM step dominates a pass; the 512 x 8 geometry would
+  // spill its register-resident samples with 8 unrolled candidates (measured 2.4x slower), so it stays at one
+  c.multi = (g.threads == 512) ? 1 : pg_candidates();
+  for (int i = 0; i < 5; ++i) c.opts[i] = a.opts ? a.opts[i] : 0.0;
+  for (int i = 0; i < kM; ++i) {
+    c.lb[i] = a.lb ? a.lb[i] : 0.0;
+    c.ub[i] = a.ub ? a.ub[i] : 0.0;
+  }
+  HIP_OK(hipMemsetAsync(queue, 0, 2 * sizeof(int), a.stream));
+  const bool fast = brdf_fast_path_enabled() || a.model == MODEL_WARD;
+  if (a.n <= kLaneMaxN && a.method == 1 && lane_path_enabled()) return lane_fit_enqueue(a.model, fast, c, queue, a.stream);
+  if (a.n <= kRowLanes && rows_path_enabled(a.method)) return rows_enqueue(a, c, fast, queue);
+  if (g.threads == 512 && big_path_enabled()) {  // 1024 < n <= 4096: control wave + seven sample waves per fit (resident_fit.hip)
+    c.multi = pg_candidates();
+    if (!fast) HIP_OK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(flags), kNeedsExact, (size_t)a.S, a.stream));
+    return resident_batch_enqueue(a.model, a.method, fast, c, a.stream);
+  }
+  const dim3 grid(a.S), block(g.threads);
+  if (fast) {
+    hipLaunchKernelGGL(kernel_for(g, a.model, a.method, true), grid, block, 0, a.stream, c);
+    HIP_OK(hipGetLastError());
+    if (a.model != MODEL_WARD) {  // fits with a cosine <= 0 marked themselves: second launch on the exact path
+      hipLaunchKernelGGL(kernel_for(g, a.model, a.method, false), grid, block, 0, a.stream, c);
+      HIP_OK(hipGetLastError());
+    }
+  } else {
+    // BRDF_HIP_EXACT_POW=1: mark every fit for the exact kernel
+    HIP_OK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(flags), kNeedsExact, (size_t)a.S, a.stream));
+    hipLaunchKernelGGL(kernel_for(g, a.model, a.method, false), grid, block, 0, a.stream, c);
+    HIP_OK(hipGetLastError());
+  }
+  return 0;
+}
+}  // namespace
 
 int batch_fit_enqueue(const BatchFitArgs &a) {
   if (a.model < 0 || a.model >= MODEL_COUNT || (a.method != 0 && a.method != 1)) {
@@ -639,73 +690,33 @@ int batch_fit_enqueue(const BatchFitArgs &a) {
               a.n);
     return kLmError;
   }
-  (void)hipGetLastError();
-  int dev = 0;
-  HIP_OK(hipGetDevice(&dev));
-  FlagBuf &fb = g_flags;
-  if (fb.device != dev || fb.cap < (size_t)a.S) {
-    if (fb.ptr) {
-      HIP_OK(hipDeviceSynchronize());  // a previous batch on another stream may still read the old buffer
-      (void)hipFree(fb.ptr);
-      fb.ptr = nullptr;
-      fb.cap = 0;
-    }
-    HIP_OK(hipMalloc(&fb.ptr, sizeof(int) * (size_t)a.S));
-    fb.cap = (size_t)a.S;
-    fb.device = dev;
-  }
-
-  BatchCtx c;
-  memset(&c, 0, sizeof c);
-  c.angles = a.d_angles;
-  c.x = a.d_x;
-  c.p = a.d_p;
-  c.info = a.d_info;
-  c.ret = a.d_ret;
-  c.flags = fb.ptr;
-  c.S = a.S;
-  c.n = a.n;
-  c.itmax = a.itmax;
-  c.has_opts = a.opts != nullptr;
-  c.has_lb = a.lb != nullptr;
-  c.has_ub = a.ub != nullptr;
-  // projected-gradient candidates per sweep: pays where the LM step dominates a pass; the 512 x 8 geometry would
-  // spill its register-resident samples with 8 unrolled candidates (measured 2.4x slower), so it stays at one
-  c.multi = (g.threads == 512) ? 1 : pg_candidates();
-  for (int i = 0; i < 5; ++i) c.opts[i] = a.opts ? a.opts[i] : 0.0;
-  for (int i = 0; i < kM; ++i) {
-    c.lb[i] = a.lb ? a.lb[i] : 0.0;
-    c.ub[i] = a.ub ? a.ub[i] : 0.0;
-  }
   if (a.method == 1 && a.lb && a.ub)
     for (int i = 0; i < kM; ++i)
       if (a.lb[i] > a.ub[i]) {  // lmbc_core.c:451-454
         set_error("dlevmar_bc_dif(): at least one lower bound exceeds the upper one");
         return kLmError;
       }
-
-  const bool fast = brdf_fast_path_enabled() || a.model == MODEL_WARD;
-  if (a.n <= kRowLanes && rows_path_enabled(a.method)) return rows_enqueue(a, c, fast);
-  if (g.threads == 512 && big_path_enabled()) {  // 1024 < n <= 4096: control wave + seven sample waves per fit (resident_fit.hip)
-    c.multi = pg_candidates();
-    if (!fast) HIP_OK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(fb.ptr), kNeedsExact, (size_t)a.S, a.stream));
-    return resident_batch_enqueue(a.model, a.method, fast, c, a.stream);
-  }
-  const dim3 grid(a.S), block(g.threads);
-  if (fast) {
-    hipLaunchKernelGGL(kernel_for(g, a.model, a.method, true), grid, block, 0, a.stream, c);
-    HIP_OK(hipGetLastError());
-    if (a.model != MODEL_WARD) {  // fits with a cosine <= 0 marked themselves: second launch on the exact path
-      hipLaunchKernelGGL(kernel_for(g, a.model, a.method, false), grid, block, 0, a.stream, c);
-      HIP_OK(hipGetLastError());
+  (void)hipGetLastError();
+  int dev = 0;
+  HIP_OK(hipGetDevice(&dev));
+  BatchScratch &sc = g_scratch;
+  if (sc.device != dev || sc.cap < (size_t)a.S) {
+    if (sc.ptr) {
+      HIP_OK(hipDeviceSynchronize());  // a previous batch (any stream) may still use the old block
+      (void)hipFree(sc.ptr);
+      if (sc.last_use) (void)hipEventDestroy(sc.last_use);
+      sc = BatchScratch{};
     }
-  } else {
-    // BRDF_HIP_EXACT_POW=1: mark every fit for the exact kernel
-    HIP_OK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(fb.ptr), kNeedsExact, (size_t)a.S, a.stream));
-    hipLaunchKernelGGL(kernel_for(g, a.model, a.method, false), grid, block, 0, a.stream, c);
-    HIP_OK(hipGetLastError());
+    HIP_OK(hipMalloc(&sc.ptr, sizeof(int) * ((size_t)a.S + 2)));
+    HIP_OK(hipEventCreateWithFlags(&sc.last_use, hipEventDisableTiming));
+    sc.cap = (size_t)a.S;
+    sc.device = dev;
   }
-  return 0;
+  if (sc.in_use) HIP_OK(hipStreamWaitEvent(a.stream, sc.last_use, 0));
+  const int rc = batch_fit_launches(a, g, sc.ptr, sc.ptr + sc.cap);
+  sc.in_use = true;  // (also after a failed enqueue: some launches may be in flight)
+  HIP_OK(hipEventRecord(sc.last_use, a.stream));
+  return rc;
 }
 
 int synth_enqueue(int model, unsigned long long seed, long long first, int count, int n, const double *d_truth,

@@ -1,0 +1,265 @@
+// lane_fit.hip -- batched regime for the application's own fit size: n <= 16 samples (16 lights per surfel,
+// brdfdata.h:58), dlevmar_bc_dif -- the call CBRDFdata::SolveEquation makes once per pixel and colour channel
+// (brdfdata.cpp:1077-1136, loop at :1195-1220).
+//
+// ONE LANE PER FIT.  At this size a fit has no data parallelism worth a wave: 16 samples x one transcendental is ~1000
+// instructions per pass, while the scalar LM step between two passes is ~2000 dependent instructions.  With one wave
+// (or one DPP row) per fit the step runs on one lane while 63 (15) idle, and it was 80-99 % of the kernel.  Here every
+// lane owns a whole fit:
+//
+//   * its LM state machine (BcMachine<3>, lm_machine.h) is a per-lane object -- 64 machines step side by side in
+//     one wave, each in its own phase (the phase switch diverges; every phase body is paid once per round for up to
+//     64 fits instead of once per fit);
+//   * its <= 16 prepared samples live in LDS, structure-of-arrays over lanes: smp[sample][plane][lane], so a lane's
+//     read of (sample, plane) is one conflict-free ds_read_b64 for the wave;
+//   * the sweep over its own samples is serial, in the REFERENCE'S summation order: the descending "small problem"
+//     loop for J^T J / J^T e (lmbc_core.c:595-615, n*m < 1024) and the four-accumulator walk of dlevmar_L2nrmxmy
+//     (misc_core.c:721-807).  No tree, no cross-lane traffic: with the exact model path the only difference left to
+//     the CPU reference is pow() itself (ocml vs glibc, last-bit);
+//   * lanes pull fits from a global queue (one wave-aggregated atomicAdd per refill), so a lane whose fit ends after
+//     10 iterations starts the next one while its neighbours are still in their line searches.
+//
+// Fits with a cosine <= 0 cannot use the cached-log path: the FAST kernel marks them (flags[]) and the exact twin,
+// launched behind it, fits exactly those with the reference's pow() -- the same protocol as batch_fit.hip.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+#include "batch_fit.h"
+#include "stream_fit.h"
+
+namespace brdf {
+
+// W = waves per SIMD the register allocator plans for (512 / 256 / 128 registers per lane at 1 / 2 / 4); LDS allows
+// 5-6 waves per CU at n = 16.  BRDF_HIP_LANE_WAVES picks the variant (measurements: DESIGN.md section 6).
+template <int MODEL, bool FAST, int W>
+__global__ __launch_bounds__(kWave, W) void lane_fit_kernel(BatchCtx ctx, int *queue) {
+  using Mdl = BrdfModel<MODEL>;
+  constexpr int NP = 3 + (Mdl::prep_planes == 2 ? 1 : 0);  // c0, q1, [q2], x
+  extern __shared__ double smp[];                          // [n][NP][64]
+  const int lane = threadIdx.x;
+  const int n = ctx.n;
+  const int S = ctx.S;
+  const double *opts = ctx.has_opts ? ctx.opts : nullptr;
+  const double *lb = ctx.has_lb ? ctx.lb : nullptr;
+  const double *ub = ctx.has_ub ? ctx.ub : nullptr;
+
+  BcMachine<kM> m;
+  m.h.req.kind = RQ_DONE;
+  int fit = -1;
+  bool more = true;  // wave-uniform: the queue may still hold fits
+  int since_heavy = 0;
+
+  // Rounds.  In a round every lane with an evaluation request sweeps its samples and steps its machine.  The EXPENSIVE
+  // things -- a Jacobian sweep with the 3x3 solve behind it, the line-search prologue (pow, square roots), the epilogue of
+  // a fit, fetching and preparing the next fit -- are needed by a lane about once per LM iteration, i.e. in ~10 % of its
+  // rounds, but with 64 lanes somebody needs each of them in EVERY round, and a wave pays for a phase body whenever one
+  // lane runs it.  So they are gated (BcMachine::run<GATED>): lanes that reach one wait, and the wave runs a "heavy" round
+  // for all of them together once a quorum waits (or nobody has anything else to do, or a lane has waited long enough).
+  // Light rounds then cost an evaluation sweep plus the cheap phases only.  Scheduling cannot change a result.
+  for (;;) {
+    const int kind0 = (fit >= 0) ? m.h.req.kind : (int)RQ_DONE;
+    const bool wants_heavy = (fit < 0 && more) || kind0 == RQ_JAC || kind0 == RQ_YIELD;
+    const bool light_work = fit >= 0 && kind0 != RQ_JAC && kind0 != RQ_YIELD;
+    const int nh = __popcll(__ballot(wants_heavy));
+    const int nl = __popcll(__ballot(light_work));
+    if (nh == 0 && nl == 0) break;
+    const bool heavy = nl == 0 || nh >= ctx.lane_quorum || since_heavy >= ctx.lane_maxwait;
+    since_heavy = heavy ? 0 : since_heavy + 1;
+
+    // ---- refill (heavy rounds): every idle lane takes the next fit of the queue ------------------------------
+    bool want = heavy && fit < 0;
+    while (more && __any(want)) {
+      const unsigned long long mask = __ballot(want);
+      const int cnt = __popcll(mask);
+      const int first = __ffsll((long long)mask) - 1;
+      int base = 0;
+      if (lane == first) base = atomicAdd(queue, cnt);
+      base = __shfl(base, first);
+      if (base + cnt >= S) more = false;
+      if (want) {
+        const int f = base + __popcll(mask & ((1ull << lane) - 1ull));
+        if (f < S && (FAST || ctx.flags[f] == kNeedsExact)) {
+          const double *a = ctx.angles + (size_t)f * 3 * n;
+          const double *xs = ctx.x + (size_t)f * n;
+          bool bad = false;
+          for (int i = 0; i < n; ++i) {
+            const double c0 = a[i];
+            const double r1 = Mdl::uses_c1 ? a[n + i] : 0.0;
+            const double r2 = Mdl::uses_c2 ? a[2 * n + i] : 0.0;
+            const Prep q = Mdl::template prepare<FAST>(c0, r1, r2);
+            if (FAST && !Mdl::domain_ok(c0, r1, r2)) bad = true;
+            double *d = smp + (size_t)i * NP * kWave + lane;
+            d[0] = c0;
+            d[kWave] = q.q1;
+            if (NP == 4) d[2 * kWave] = q.q2;
+            d[(NP - 1) * kWave] = xs[i];
+          }
+          if (FAST) ctx.flags[f] = bad ? kNeedsExact : 0;
+          if (!(FAST && bad)) {
+            m.start(ctx.p + (size_t)f * kM, n, lb, ub, nullptr, ctx.itmax, opts, 0, 1);
+            if (m.h.req.kind == RQ_DONE) {  // refused by start() (n < m, inconsistent box): lmbc_core.c:440-454
+              if (ctx.ret) ctx.ret[f] = kLmError;
+              if (ctx.info)
+                for (int i = 0; i < kInfoSz; ++i) ctx.info[(size_t)f * kInfoSz + i] = 0.0;
+            } else {
+              fit = f;
+              want = false;
+            }
+          }
+        }
+        if (f >= S) want = false;  // nothing left for this lane
+      }
+    }
+
+    if (fit >= 0) {
+      // ---- one pass over this lane's samples, sums in the reference's order -----------------------------------
+      const Request<kM> &r = m.h.req;
+      const int kind = r.kind;
+      double s[kSlots];
+#pragma unroll
+      for (int k = 0; k < kSlots; ++k) s[k] = 0.0;
+      double mx = 0.0;
+      const double *sp = smp + lane;
+      bool do_step = false;
+      if (kind == RQ_JAC) {
+        if (heavy) {  // lmbc_core.c:595-615: for l = n-1..0 { jtj[i][j] += row[j]*row[i]; jte[i] += row[i]*e[l] }
+          PassUniforms<MODEL> u;
+          u.build(r, true, false);
+          for (int l = n; l-- > 0;) {
+            const double *d = sp + (size_t)l * NP * kWave;
+            const Prep q{d[kWave], NP == 4 ? d[2 * kWave] : 0.0};
+            double f0 = 0.0, j[kM];
+            model_fd_row<MODEL, FAST>(u, d[0], q, true, f0, 0.0, false, j);
+            const double e = d[(NP - 1) * kWave] - f0;
+            acc_normal_eq(j, e, s, s + kNL);
+          }
+          do_step = true;
+        }
+      } else if (kind == RQ_YIELD) {
+        do_step = heavy;
+      } else {
+        PassUniforms<MODEL> u;  // an evaluation reads l0, n0 (and scal) only
+        u.l0 = Mdl::lin(r.p);
+        u.n0 = Mdl::nl(r.p);
+        u.scal = r.scal;
+        if (kind == RQ_SCALED) {  // lmbc_core.c:163-166, descending
+          for (int l = n; l-- > 0;) {
+            const double *d = sp + (size_t)l * NP * kWave;
+            const Prep q{d[kWave], NP == 4 ? d[2 * kWave] : 0.0};
+            const double t = (d[(NP - 1) * kWave] - model_value<MODEL, FAST>(u, d[0], q)) / u.scal;
+            s[0] += t * t;
+          }
+        } else {  // RQ_EVAL: misc_core.c:721-807 -- blocks of 8 from the top down, accumulator (top - j) & 3; then the tail upwards
+          double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+          const int body = (n >> 3) << 3;
+          for (int jb = body - 4; jb >= 0; jb -= 4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const double *d = sp + (size_t)(jb + 3 - k) * NP * kWave;
+              const Prep q{d[kWave], NP == 4 ? d[2 * kWave] : 0.0};
+              const double e = d[(NP - 1) * kWave] - model_value<MODEL, FAST>(u, d[0], q);
+              const double e2 = e * e;
+              if (k == 0) a0 += e2;
+              if (k == 1) a1 += e2;
+              if (k == 2) a2 += e2;
+              if (k == 3) a3 += e2;
+              mx = fmax(mx, fabs(e));
+            }
+          }
+          for (int t = body; t < n; ++t) {
+            const double *d = sp + (size_t)t * NP * kWave;
+            const Prep q{d[kWave], NP == 4 ? d[2 * kWave] : 0.0};
+            const double e = d[(NP - 1) * kWave] - model_value<MODEL, FAST>(u, d[0], q);
+            const double e2 = e * e;
+            const int k = (7 - (n - t)) & 3;
+            a0 += (k == 0) ? e2 : 0.0;
+            a1 += (k == 1) ? e2 : 0.0;
+            a2 += (k == 2) ? e2 : 0.0;
+            a3 += (k == 3) ? e2 : 0.0;
+            mx = fmax(mx, fabs(e));
+          }
+          s[0] = a0 + a1 + a2 + a3;
+        }
+        do_step = true;
+      }
+      if (do_step) {
+        m.template step<false, false, true>(s, mx, heavy);
+        if (m.h.req.kind == RQ_DONE) {
+          double *po = ctx.p + (size_t)fit * kM;
+          for (int i = 0; i < kM; ++i) po[i] = m.h.p[i];
+          if (ctx.info)
+            for (int i = 0; i < kInfoSz; ++i) ctx.info[(size_t)fit * kInfoSz + i] = m.c.info[i];
+          if (ctx.ret) ctx.ret[fit] = m.c.ret;
+          fit = -1;
+        }
+      }
+    }
+  }
+}
+
+#define HIP_OK(call)                                                                  \
+  do {                                                                                \
+    hipError_t e_ = (call);                                                           \
+    if (e_ != hipSuccess) {                                                           \
+      set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return kLmError;                                                                \
+    }                                                                                 \
+  } while (0)
+
+namespace {
+using LaneFn = void (*)(BatchCtx, int *);
+template <int W>
+LaneFn lane_kernel_w(int model, bool fast) {
+  static const LaneFn table[2][MODEL_COUNT] = {
+      {lane_fit_kernel<0, false, W>, lane_fit_kernel<1, false, W>, nullptr},  // Ward's prepared path has no domain restriction
+      {lane_fit_kernel<0, true, W>, lane_fit_kernel<1, true, W>, lane_fit_kernel<2, true, W>},
+  };
+  return table[fast ? 1 : 0][model];
+}
+int lane_waves_per_simd() {
+  const char *e = getenv("BRDF_HIP_LANE_WAVES");
+  const int w = e ? atoi(e) : 2;
+  return (w == 1 || w == 4) ? w : 2;
+}
+LaneFn lane_kernel(int model, bool fast, int w) {
+  return w == 1 ? lane_kernel_w<1>(model, fast) : (w == 4 ? lane_kernel_w<4>(model, fast) : lane_kernel_w<2>(model, fast));
+}
+}  // namespace
+
+// dlevmar_bc_dif, n <= kLaneMaxN.  c.flags: S ints; queue: 2 ints, zeroed by the caller on `stream`.
+int lane_fit_enqueue(int model, bool fast, const BatchCtx &c, int *queue, hipStream_t stream) {
+  int dev = 0;
+  HIP_OK(hipGetDevice(&dev));
+  int cus = 0;
+  HIP_OK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  const int np = (model == MODEL_WARD) ? 4 : 3;
+  const size_t lds = sizeof(double) * (size_t)c.n * np * kWave;
+  const int w = lane_waves_per_simd();
+  long long per_cu = (160 * 1024) / (long long)std::max<size_t>(lds, 1);
+  if (per_cu > 4 * w) per_cu = 4 * w;
+  if (per_cu < 1) per_cu = 1;
+  BatchCtx cc = c;
+  cc.lane_quorum = 16;
+  cc.lane_maxwait = 6;
+  if (const char *e = getenv("BRDF_HIP_LANE_QUORUM")) cc.lane_quorum = std::max(1, atoi(e));
+  if (const char *e = getenv("BRDF_HIP_LANE_MAXWAIT")) cc.lane_maxwait = std::max(0, atoi(e));
+  long long waves = (long long)cus * per_cu;
+  const long long need = ((long long)c.S + kWave - 1) / kWave;
+  if (waves > need) waves = need;
+  if (fast) {
+    hipLaunchKernelGGL(lane_kernel(model, true, w), dim3((unsigned)waves), dim3(kWave), lds, stream, cc, queue);
+    HIP_OK(hipGetLastError());
+    if (model != MODEL_WARD) {  // (a launch over an empty set costs one queue sweep: every lane's first fetch finds no marked fit)
+      hipLaunchKernelGGL(lane_kernel(model, false, w), dim3((unsigned)waves), dim3(kWave), lds, stream, cc, queue + 1);
+      HIP_OK(hipGetLastError());
+    }
+  } else {
+    HIP_OK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c.flags), kNeedsExact, (size_t)c.S, stream));
+    hipLaunchKernelGGL(lane_kernel(model, false, w), dim3((unsigned)waves), dim3(kWave), lds, stream, cc, queue);
+    HIP_OK(hipGetLastError());
+  }
+  return 0;
+}
+
+}  // namespace brdf

@@ -41,6 +41,16 @@ constexpr double kInitMu = 1E-03;
 #define LM_STAMP(i) do {} while (0)  // diagnostic builds (-DBRDF_STAMPS) time the sections of a step
 #endif
 
+// a guarded phase block of BcMachine::run (see there); ONE_LANE: the comparison stays on the scalar unit
+#define LM_PHASE(X) if ((ONE_LANE ? lm_uniform(ph) : ph) == X) do
+#define LM_PHASE_END while (0);
+// in front of a gated block: a GATED step outside a heavy round stops here (RQ_YIELD)
+#define LM_GATE(X)                                    \
+  if (GATED && !heavy && ph == X) {                   \
+    h.req.kind = RQ_YIELD;                            \
+    { h.phase = ph; return; }                         \
+  }
+
 constexpr double kStopThresh = 1E-17;
 constexpr double kDiffDelta = 1E-06;
 constexpr int kInfoSz = 10;
@@ -58,8 +68,10 @@ enum ReqKind : int {
                      // two-step:     wrk <- f(q); sums = [sum e_new^2]
   RQ_DIF_UPDATE = 7, // two-step only: J <- Broyden(J, wrk, hx); sums = [JTJ lower, JT e] with e = x-wrk if
                      //   aux (step accepted) else x-hx; finally hx <- wrk if aux
-  RQ_EVAL_MULTI = 8  // sums[j] = sum (x-f(pk[j]))^2 for j < nk: several candidates of a projected-gradient search
+  RQ_EVAL_MULTI = 8, // sums[j] = sum (x-f(pk[j]))^2 for j < nk: several candidates of a projected-gradient search
                      //   in ONE sweep (the samples are read once; a pass's fixed cost is paid once)
+  RQ_YIELD = 9       // no pass: a GATED step (BcMachine::run) stopped in front of an expensive phase; call step() again
+                     //   with heavy = true (lane_fit.hip runs the expensive phases of its 64 machines in common rounds)
 };
 
 constexpr int kMaxCand = 8;  // candidates per RQ_EVAL_MULTI
@@ -604,7 +616,7 @@ struct DifMachine {
 template <int M>
 struct BcMachine {
   enum Phase : int {
-    B_INIT_EVAL = 1, B_ITER_TOP, B_AFTER_JAC, B_SOLVE, B_AFTER_LM_EVAL, B_AFTER_LM_NORM, B_LM_JUDGE,
+    B_INIT_EVAL = 1, B_ITER_TOP, B_AFTER_JAC, B_SOLVE, B_AFTER_LM_EVAL, B_AFTER_LM_NORM, B_LM_JUDGE, B_LS_PROLOGUE,
     B_LS_ISSUE, B_LS_EVAL, B_PG_BEGIN, B_PG_ISSUE, B_PG_EVAL, B_PG_NORM, B_PG_JUDGE, B_PG_MULTI, B_COMMIT,
     B_END_ITER, B_FINISH, B_DONE
   };
@@ -754,17 +766,30 @@ struct BcMachine {
     h.p_e2 = h.pdp_e2;
   }
 
-  template <bool ONE_LANE = false>
-  LM_HD void step(const double *s, double maxabs) { run<ONE_LANE>(c, h, s, maxabs); }
+  // MULTI = false compiles the multi-candidate projected-gradient machinery out (callers that start with multi = 1).
+  // GATED: the expensive phases -- everything behind a Jacobian pass (B_AFTER_JAC, B_SOLVE: the 3x3 LU), the line-search
+  // prologue (pow, square roots, divisions) and B_FINISH -- only run when `heavy` is set; otherwise the step stops in front
+  // of them with RQ_YIELD.  Pure scheduling: a machine's trajectory does not depend on when its phases run.
+  template <bool ONE_LANE = false, bool MULTI = true, bool GATED = false>
+  LM_HD void step(const double *s, double maxabs, bool heavy = true) { run<ONE_LANE, MULTI, GATED>(c, h, s, maxabs, heavy); }
 
-  template <bool ONE_LANE>
-  static LM_HD void run(Cold &c, Hot &h, const double *s, double maxabs) {
+  template <bool ONE_LANE, bool MULTI, bool GATED>
+  static LM_HD void run(Cold &c, Hot &h, const double *s, double maxabs, bool heavy) {
     constexpr double alpha = 1e-4, beta = 0.9, gamma = 0.99995, rho = 1e-8, tming = 1e-18, tini = 1.0;
     int ph = ONE_LANE ? lm_uniform(h.phase) : h.phase;  // scalar register: phase transitions become scalar jumps
     for (;;) {
       if (ONE_LANE) ph = lm_uniform(ph);  // re-assert uniformity: assignments under (formally) divergent branches lose it
-      switch (ph) {
-      case B_INIT_EVAL:  // lmbc_core.c:523-540
+      // The phases are a chain of guarded blocks in the order control flows through them, not a switch: a lane (or
+      // the one stepping lane) walks through every block its phase reaches in ONE trip of this loop -- only a failed
+      // 3x3 solve (B_SOLVE again) needs a second trip.  That matters where 64 machines step side by side in the lanes
+      // of one wave (lane_fit.hip): a switch inside a loop executes every phase body once per trip and a lane takes 2-5
+      // trips per step, i.e. the expensive bodies (LU, line-search interpolation, pow) would run several times per step.
+      // `break` inside a block leaves the block (do { } while (0)), exactly as it left the switch before.
+      if (ph <= 0 || ph >= B_DONE) {
+        h.req.kind = RQ_DONE;
+        { h.phase = ph; return; }
+      }
+      LM_PHASE(B_INIT_EVAL) {  // lmbc_core.c:523-540
         h.nfev = 1;
         h.p_e2 = s[0];
         h.init_e2 = h.p_e2;
@@ -777,28 +802,11 @@ struct BcMachine {
           }
         ph = B_ITER_TOP;
         break;
+      } LM_PHASE_END
 
-      case B_ITER_TOP: {
-        if (!(h.k < c.itmax && !h.stop)) {
-          ph = B_FINISH;
-          break;
-        }
-        if (h.p_e2 <= c.o.eps3) {
-          h.stop = 6;
-          ph = B_FINISH;
-          break;
-        }
-        clear_req(h);  // FD Jacobian at the unscaled point, lmbc_core.c:555-561 + :1043-1054
-        h.req.kind = RQ_JAC;
-        h.req.central = !c.o.forward;
-        for (int i = 0; i < M; ++i) h.req.p[i] = c.has_dscl ? h.p[i] * c.dscl[i] : h.p[i];
-        fd_steps<M>(h.req.p, c.o.delta, h.req.d);
-        ++h.njev;
-        ph = B_AFTER_JAC;
-        { h.phase = ph; return; }
-      }
-
-      case B_AFTER_JAC: {
+      LM_GATE(B_AFTER_JAC)
+      if (!GATED || heavy)
+      LM_PHASE(B_AFTER_JAC) {
         unpack_lower<M>(s, h.jtj);
         for (int i = 0; i < M; ++i) h.jte[i] = s[SumLayout<M>::NL + i];
         if (c.has_dscl) {  // J <- J*D (lmbc_core.c:562-569) folded into the reduced products
@@ -840,9 +848,11 @@ struct BcMachine {
         }
         ph = B_SOLVE;
         break;
-      }
+      } LM_PHASE_END
 
-      case B_SOLVE: {  // lmbc_core.c:677-734
+      LM_GATE(B_SOLVE)
+      if (!GATED || heavy)
+      LM_PHASE(B_SOLVE) {  // lmbc_core.c:677-734
         for (int i = 0; i < M; ++i) h.jtj[i * M + i] += h.mu;
         const int solved = lu_solve<M>(h.jtj, h.jte, h.dp);
         ++h.nlss;
@@ -885,9 +895,9 @@ struct BcMachine {
         request_eval(c, h, v);
         ph = B_AFTER_LM_EVAL;
         { h.phase = ph; return; }
-      }
+      } LM_PHASE_END
 
-      case B_AFTER_LM_EVAL:  // overflow guard, lmbc_core.c:748-751
+      LM_PHASE(B_AFTER_LM_EVAL) {  // overflow guard, lmbc_core.c:748-751
         h.pdp_e2 = s[0];
         if (!lm_finite(h.pdp_e2)) {
           if (!lm_finite(maxabs)) {
@@ -904,8 +914,9 @@ struct BcMachine {
         }
         ph = B_LM_JUDGE;
         break;
+      } LM_PHASE_END
 
-      case B_AFTER_LM_NORM:
+      LM_PHASE(B_AFTER_LM_NORM) {
         if (!lm_finite(h.keep_max * sqrt(s[0]))) {
           h.stop = 7;
           ph = B_END_ITER;
@@ -913,8 +924,9 @@ struct BcMachine {
         }
         ph = B_LM_JUDGE;
         break;
+      } LM_PHASE_END
 
-      case B_LM_JUDGE: {
+      LM_PHASE(B_LM_JUDGE) {
         if (h.pdp_e2 <= gamma * h.p_e2) {  // LM step taken, lmbc_core.c:753-785
           double dL = 0.0;
           for (int i = 0; i < M; ++i) dL += h.dp[i] * (h.mu * h.dp[i] + h.jte[i]);
@@ -933,6 +945,13 @@ struct BcMachine {
           ph = B_END_ITER;
           break;
         }
+        ph = B_LS_PROLOGUE;
+        break;
+      } LM_PHASE_END
+
+      LM_GATE(B_LS_PROLOGUE)
+      if (!GATED || heavy)
+      LM_PHASE(B_LS_PROLOGUE) {  // the LM step was rejected
         h.gdp = 0.0;  // lmbc_core.c:811-816
         for (int i = 0; i < M; ++i) {
           h.jte[i] = -h.jte[i];
@@ -970,38 +989,9 @@ struct BcMachine {
         h.ls_left = kLsItMax;
         ph = B_LS_ISSUE;
         break;
-      }
+      } LM_PHASE_END
 
-      case B_LS_ISSUE: {  // lmbc_core.c:253-266
-        if (h.ls_left-- <= 0) {  // iteration limit: failure -> projected gradient
-          ph = B_PG_BEGIN;
-          break;
-        }
-        double v[M];
-        const double lam = h.ls_lambda;
-        for (int i = M; i-- > 0;) v[i] = h.p[i] + lam * h.dp[i];
-        project(c, v);
-        h.req.kind = RQ_EVAL;
-        h.req.scal = 1.0;
-        if (!c.has_dscl) {
-          for (int i = 0; i < M; ++i) {
-            h.req.p[i] = v[i];
-            h.pdp[i] = v[i];
-          }
-        } else {  // the reference multiplies and divides xpls in place, lmbc_core.c:263-265
-          for (int i = M; i-- > 0;) {
-            v[i] *= c.dscl[i];
-            h.req.p[i] = v[i];
-            v[i] /= c.dscl[i];
-            h.pdp[i] = v[i];
-          }
-        }
-        ++h.nfev;
-        ph = B_LS_EVAL;
-        { h.phase = ph; return; }
-      }
-
-      case B_LS_EVAL: {  // lmbc_core.c:269-332
+      LM_PHASE(B_LS_EVAL) {  // lmbc_core.c:269-332
         const double fpls = 0.5 * s[0];
         h.pdp_e2 = s[0];
         if (fpls <= h.ls_f0 + h.ls_slp * alpha * h.ls_lambda) {  // satisfactory point
@@ -1046,69 +1036,70 @@ struct BcMachine {
         }
         ph = B_LS_ISSUE;
         break;
-      }
+      } LM_PHASE_END
 
-      case B_PG_BEGIN: {  // lmbc_core.c:877-885 (jte already holds -J^T e)
-        double g2 = 0.0;
-        for (int i = 0; i < M; ++i) g2 += h.jte[i] * h.jte[i];
-        g2 = sqrt(g2);
-        g2 = 100.0 / (1.0 + g2);
-        h.t0 = (g2 <= tini) ? g2 : tini;
-        h.t = h.gprev ? h.t : h.t0;
-        ph = B_PG_ISSUE;
-        break;
-      }
-
-      case B_PG_ISSUE: {  // loop head of lmbc_core.c:885
-        if (!(h.t > tming)) {  // search failed, :937-939
-          h.gprev = 0;
-          ph = B_END_ITER;
+      LM_PHASE(B_LS_ISSUE) {  // lmbc_core.c:253-266
+        if (h.ls_left-- <= 0) {  // iteration limit: failure -> projected gradient
+          ph = B_PG_BEGIN;
           break;
         }
-        double pc[M], g[M];
-        for (int i = 0; i < M; ++i) {
-          pc[i] = h.p[i];
-          g[i] = h.jte[i];
+        double v[M];
+        const double lam = h.ls_lambda;
+        for (int i = M; i-- > 0;) v[i] = h.p[i] + lam * h.dp[i];
+        project(c, v);
+        h.req.kind = RQ_EVAL;
+        h.req.scal = 1.0;
+        if (!c.has_dscl) {
+          for (int i = 0; i < M; ++i) {
+            h.req.p[i] = v[i];
+            h.pdp[i] = v[i];
+          }
+        } else {  // the reference multiplies and divides xpls in place, lmbc_core.c:263-265
+          for (int i = M; i-- > 0;) {
+            v[i] *= c.dscl[i];
+            h.req.p[i] = v[i];
+            v[i] /= c.dscl[i];
+            h.pdp[i] = v[i];
+          }
         }
-        const int want = h.pg_single ? 1 : c.multi;
-        h.pg_single = 0;
-        double tt = h.t;
-        int cnt = 0;
-        double v0[M];
-        for (int j = 0; j < kMaxCand; ++j) {  // t, t*beta, t*beta^2, ... exactly as the loop increment forms them
-          if (j >= want || !(tt > tming)) break;
+        ++h.nfev;
+        ph = B_LS_EVAL;
+        { h.phase = ph; return; }
+      } LM_PHASE_END
+
+      LM_PHASE(B_PG_EVAL) {
+        h.pdp_e2 = s[0];
+        if (!lm_finite(h.pdp_e2)) {  // lmbc_core.c:915-918
+          if (!lm_finite(maxabs)) {
+            h.stop = 7;
+            ph = B_FINISH;
+            break;
+          }
+          h.keep_max = maxabs;
           double v[M];
-          for (int i = 0; i < M; ++i) v[i] = pc[i] - tt * g[i];
-          project(c, v);
-          for (int i = 0; i < M; ++i) {
-            if (j == 0) v0[i] = v[i];
-            h.req.pk[j][i] = c.has_dscl ? v[i] * c.dscl[i] : v[i];
-          }
-          ++cnt;
-          tt *= beta;
-        }
-        if (cnt <= 1) {  // one candidate: the plain evaluation request
-          double l2 = 0.0;
-          for (int i = 0; i < M; ++i) {
-            const double d = v0[i] - pc[i];
-            h.pdp[i] = v0[i];
-            h.dp[i] = d;
-            l2 += d * d;
-          }
-          h.dp_l2 = l2;
-          request_eval(c, h, v0);
-          ph = B_PG_EVAL;
+          for (int i = 0; i < M; ++i) v[i] = h.pdp[i];
+          request_eval(c, h, v, RQ_SCALED);
+          --h.nfev;
+          h.req.scal = maxabs;
+          ph = B_PG_NORM;
           { h.phase = ph; return; }
         }
-        h.pg_n = cnt;
-        h.req.kind = RQ_EVAL_MULTI;
-        h.req.nk = cnt;
-        h.req.scal = 1.0;
-        ph = B_PG_MULTI;
-        { h.phase = ph; return; }
-      }
+        ph = B_PG_JUDGE;
+        break;
+      } LM_PHASE_END
 
-      case B_PG_MULTI: {  // judge the candidates of one sweep in the reference's order (lmbc_core.c:886-935)
+      LM_PHASE(B_PG_NORM) {
+        if (!lm_finite(h.keep_max * sqrt(s[0]))) {
+          h.stop = 7;
+          ph = B_FINISH;  // "goto breaknested": k is not advanced
+          break;
+        }
+        ph = B_PG_JUDGE;
+        break;
+      } LM_PHASE_END
+
+      if constexpr (MULTI)
+      LM_PHASE(B_PG_MULTI) {  // judge the candidates of one sweep in the reference's order (lmbc_core.c:886-935)
         double pc[M], g[M];
         for (int i = 0; i < M; ++i) {
           pc[i] = h.p[i];
@@ -1157,38 +1148,9 @@ struct BcMachine {
         h.t = tt;
         ph = next;
         break;
-      }
+      } LM_PHASE_END
 
-      case B_PG_EVAL:
-        h.pdp_e2 = s[0];
-        if (!lm_finite(h.pdp_e2)) {  // lmbc_core.c:915-918
-          if (!lm_finite(maxabs)) {
-            h.stop = 7;
-            ph = B_FINISH;
-            break;
-          }
-          h.keep_max = maxabs;
-          double v[M];
-          for (int i = 0; i < M; ++i) v[i] = h.pdp[i];
-          request_eval(c, h, v, RQ_SCALED);
-          --h.nfev;
-          h.req.scal = maxabs;
-          ph = B_PG_NORM;
-          { h.phase = ph; return; }
-        }
-        ph = B_PG_JUDGE;
-        break;
-
-      case B_PG_NORM:
-        if (!lm_finite(h.keep_max * sqrt(s[0]))) {
-          h.stop = 7;
-          ph = B_FINISH;  // "goto breaknested": k is not advanced
-          break;
-        }
-        ph = B_PG_JUDGE;
-        break;
-
-      case B_PG_JUDGE: {  // lmbc_core.c:923-935
+      LM_PHASE(B_PG_JUDGE) {  // lmbc_core.c:923-935
         double g = 0.0;
         for (int i = 0; i < M; ++i) g += h.jte[i] * h.dp[i];
         h.gdp = g;
@@ -1209,9 +1171,69 @@ struct BcMachine {
         h.t = h.t * beta;
         ph = B_PG_ISSUE;
         break;
-      }
+      } LM_PHASE_END
 
-      case B_COMMIT: {  // lmbc_core.c:950-967
+      LM_PHASE(B_PG_BEGIN) {  // lmbc_core.c:877-885 (jte already holds -J^T e)
+        double g2 = 0.0;
+        for (int i = 0; i < M; ++i) g2 += h.jte[i] * h.jte[i];
+        g2 = sqrt(g2);
+        g2 = 100.0 / (1.0 + g2);
+        h.t0 = (g2 <= tini) ? g2 : tini;
+        h.t = h.gprev ? h.t : h.t0;
+        ph = B_PG_ISSUE;
+        break;
+      } LM_PHASE_END
+
+      LM_PHASE(B_PG_ISSUE) {  // loop head of lmbc_core.c:885
+        if (!(h.t > tming)) {  // search failed, :937-939
+          h.gprev = 0;
+          ph = B_END_ITER;
+          break;
+        }
+        double pc[M], g[M];
+        for (int i = 0; i < M; ++i) {
+          pc[i] = h.p[i];
+          g[i] = h.jte[i];
+        }
+        const int want = MULTI ? (h.pg_single ? 1 : c.multi) : 1;
+        h.pg_single = 0;
+        double tt = h.t;
+        int cnt = 0;
+        double v0[M];
+        for (int j = 0; j < kMaxCand; ++j) {  // t, t*beta, t*beta^2, ... exactly as the loop increment forms them
+          if (j >= want || !(tt > tming)) break;
+          double v[M];
+          for (int i = 0; i < M; ++i) v[i] = pc[i] - tt * g[i];
+          project(c, v);
+          for (int i = 0; i < M; ++i) {
+            if (j == 0) v0[i] = v[i];
+            h.req.pk[j][i] = c.has_dscl ? v[i] * c.dscl[i] : v[i];
+          }
+          ++cnt;
+          tt *= beta;
+        }
+        if (cnt <= 1) {  // one candidate: the plain evaluation request
+          double l2 = 0.0;
+          for (int i = 0; i < M; ++i) {
+            const double d = v0[i] - pc[i];
+            h.pdp[i] = v0[i];
+            h.dp[i] = d;
+            l2 += d * d;
+          }
+          h.dp_l2 = l2;
+          request_eval(c, h, v0);
+          ph = B_PG_EVAL;
+          { h.phase = ph; return; }
+        }
+        h.pg_n = cnt;
+        h.req.kind = RQ_EVAL_MULTI;
+        h.req.nk = cnt;
+        h.req.scal = 1.0;
+        ph = B_PG_MULTI;
+        { h.phase = ph; return; }
+      } LM_PHASE_END
+
+      LM_PHASE(B_COMMIT) {  // lmbc_core.c:950-967
         h.dp_l2 = 0.0;
         for (int i = 0; i < M; ++i) {
           const double d = h.pdp[i] - h.p[i];
@@ -1225,14 +1247,37 @@ struct BcMachine {
         accept_trial(h);
         ph = B_END_ITER;
         break;
-      }
+      } LM_PHASE_END
 
-      case B_END_ITER:
+      LM_PHASE(B_END_ITER) {
         ++h.k;
         ph = B_ITER_TOP;
         break;
+      } LM_PHASE_END
 
-      case B_FINISH: {  // lmbc_core.c:973-1021, :1119-1124
+      LM_PHASE(B_ITER_TOP) {
+        if (!(h.k < c.itmax && !h.stop)) {
+          ph = B_FINISH;
+          break;
+        }
+        if (h.p_e2 <= c.o.eps3) {
+          h.stop = 6;
+          ph = B_FINISH;
+          break;
+        }
+        clear_req(h);  // FD Jacobian at the unscaled point, lmbc_core.c:555-561 + :1043-1054
+        h.req.kind = RQ_JAC;
+        h.req.central = !c.o.forward;
+        for (int i = 0; i < M; ++i) h.req.p[i] = c.has_dscl ? h.p[i] * c.dscl[i] : h.p[i];
+        fd_steps<M>(h.req.p, c.o.delta, h.req.d);
+        ++h.njev;
+        ph = B_AFTER_JAC;
+        { h.phase = ph; return; }
+      } LM_PHASE_END
+
+      LM_GATE(B_FINISH)
+      if (!GATED || heavy)
+      LM_PHASE(B_FINISH) {  // lmbc_core.c:973-1021, :1119-1124
         if (h.k >= c.itmax) h.stop = 3;
         for (int i = 0; i < M; ++i) h.jtj[i * M + i] = h.diag[i];
         c.info[0] = h.init_e2;
@@ -1260,12 +1305,7 @@ struct BcMachine {
         clear_req(h);
         ph = B_DONE;
         { h.phase = ph; return; }
-      }
-
-      default:
-        h.req.kind = RQ_DONE;
-        { h.phase = ph; return; }
-      }
+      } LM_PHASE_END
     }
   }
 };
