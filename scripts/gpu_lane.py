@@ -53,11 +53,11 @@ for model in (1, 2):
     variants = [("wave_per_fit", {"BRDF_HIP_LANE": "0"})]
     for w in ("1", "2", "4"):
         variants.append((f"lane_w{w}", {"BRDF_HIP_LANE": "1", "BRDF_HIP_LANE_WAVES": w}))
-    for q, mw in ((1, 0), (8, 3), (8, 6), (16, 12), (32, 6), (32, 12), (48, 16)):
-        variants.append((f"lane_w2_q{q}_mw{mw}", {"BRDF_HIP_LANE": "1", "BRDF_HIP_LANE_WAVES": "2", "BRDF_HIP_LANE_QUORUM": str(q),
+    for q, mw in ((1, 0), (8, 3), (16, 6), (24, 6), (32, 6), (32, 12), (40, 8)):
+        variants.append((f"lane_w1_q{q}_mw{mw}", {"BRDF_HIP_LANE": "1", "BRDF_HIP_LANE_WAVES": "1", "BRDF_HIP_LANE_QUORUM": str(q),
                                                     "BRDF_HIP_LANE_MAXWAIT": str(mw)}))
     if model != 2:
-        variants.append(("lane_w2_exact_pow", {"BRDF_HIP_LANE": "1", "BRDF_HIP_LANE_WAVES": "2", "BRDF_HIP_EXACT_POW": "1"}))
+        variants.append(("lane_w1_exact_pow", {"BRDF_HIP_LANE": "1", "BRDF_HIP_LANE_WAVES": "1", "BRDF_HIP_EXACT_POW": "1"}))
     for name, env in variants:
         for k in ("BRDF_HIP_LANE", "BRDF_HIP_LANE_WAVES", "BRDF_HIP_EXACT_POW", "BRDF_HIP_LANE_QUORUM", "BRDF_HIP_LANE_MAXWAIT"):
             os.environ.pop(k, None)
