@@ -56,6 +56,7 @@ ABI = {
     "brdf_hip_last_error": (C.c_char_p, []),
     "brdf_hip_last_fit_launches": (C.c_longlong, []),
     "brdf_hip_last_fit_stamps": (C.c_int, [C.POINTER(C.c_longlong)]),
+    "brdf_hip_last_fit_trace": (C.c_int, [C.POINTER(C.c_longlong), C.c_int]),
     "brdf_hip_last_fit_stats": (C.c_int, [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong),
                                           D]),
 }

@@ -415,6 +415,9 @@ int brdf_hip_last_fit_stats(long long *passes, long long *jac_passes, long long 
 
 long long brdf_hip_last_fit_launches(void) { return stream_fit_last_stats().launches; }
 
+/* diagnostic builds (-DBRDF_STAMPS) only: one epoch's timeline of every workgroup of the last resident fit */
+int brdf_hip_last_fit_trace(long long *out, int max_rows) { return resident_fit_last_trace(out, max_rows); }
+
 /* diagnostic builds (-DBRDF_STAMPS) only: cycles per section of the pass kernel, summed over passes */
 int brdf_hip_last_fit_stamps(long long *out8) {
   const FitStats s = stream_fit_last_stats();

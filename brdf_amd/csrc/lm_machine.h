@@ -47,7 +47,7 @@ constexpr double kInitMu = 1E-03;
 // in front of a gated block: a GATED step outside a heavy round stops here (RQ_YIELD)
 #define LM_GATE(X)                                    \
   if (GATED && !heavy && ph == X) {                   \
-    h.req.kind = RQ_YIELD;                            \
+    req.kind = RQ_YIELD;                              \
     { h.phase = ph; return; }                         \
   }
 
@@ -309,18 +309,46 @@ struct DifMachine {
     double info[kInfoSz], covar[M * M];
     int ret;
   };
-  struct Hot {
+  struct Core {  // everything an LM step reads or writes, except the request it leaves
     int phase, k, stop, nu, nfev, njap, nlss, updjac, updp, newjac;
     int sel_hx, sel_j, accepted;
-    double p[M], mu, p_e2, init_e2, jte_inf, p_l2, dp_l2, pdp_e2;
-    double jtj[M * M], jte[M], diag[M], dp[M], pdp[M];
+    double p[M], mu, p_e2, jte_inf, p_l2, dp_l2, pdp_e2;
+    double jtj[M * M], jte[M], dp[M];
+  };
+  struct Cool {  // the less busy half of the state (see Hot)
+    double init_e2, diag[M], pdp[M];
     double spec_jtj[M * M], spec_jte[M];  // normal equations of the Broyden-updated J, adopted lazily
+  };
+  // Core + Cool + the request.  run() takes them separately, so that a kernel can step on a REGISTER copy of Core
+  // while the rest stays in LDS (resident_fit.hip: the sweeping waves read the request there; with Cool in registers as
+  // well, hipcc spilled ~100 VGPRs of the step to scratch, which cost more than the LDS round trips it saved)
+  struct Hot : Core {
+    Cool cool;
     Request<M> req;
   };
+  // where ONE machine is stepped by a whole wave (every lane the same values): moves the counters and flags of a
+  // register copy into scalar registers, so that the step's integer logic and branches run on the scalar unit
+  static LM_HD void uniform_ints(Core &h) {
+    h.phase = lm_uniform(h.phase);
+    h.k = lm_uniform(h.k);
+    h.stop = lm_uniform(h.stop);
+    h.nu = lm_uniform(h.nu);
+    h.nfev = lm_uniform(h.nfev);
+    h.njap = lm_uniform(h.njap);
+    h.nlss = lm_uniform(h.nlss);
+    h.updjac = lm_uniform(h.updjac);
+    h.updp = lm_uniform(h.updp);
+    h.newjac = lm_uniform(h.newjac);
+    h.sel_hx = lm_uniform(h.sel_hx);
+    h.sel_j = lm_uniform(h.sel_j);
+    h.accepted = lm_uniform(h.accepted);
+  }
   Cold c;
   Hot h;
 
   LM_HD void start(const double *p0, int n_, int itmax_, const double *opts, int want_covar_, int speculative_ = 1) {
+    Request<M> &req = h.req;
+    Cool &cool = h.cool;
     c.o = make_options(opts);
     c.speculative = speculative_;
     h.accepted = 0;
@@ -336,54 +364,54 @@ struct DifMachine {
     c.refresh = (M >= 10) ? M : 10;  // "K", lm_core.c:495
     h.sel_hx = h.sel_j = 0;
     h.mu = h.jte_inf = h.p_l2 = 0.0;
-    h.p_e2 = h.init_e2 = h.pdp_e2 = 0.0;
+    h.p_e2 = cool.init_e2 = h.pdp_e2 = 0.0;
     h.dp_l2 = DBL_MAX;
     c.ret = kLmError;
     for (int i = 0; i < M; ++i) {
       h.p[i] = p0[i];
-      h.jte[i] = h.diag[i] = h.dp[i] = h.pdp[i] = 0.0;
-      h.spec_jte[i] = 0.0;
+      h.jte[i] = cool.diag[i] = h.dp[i] = cool.pdp[i] = 0.0;
+      cool.spec_jte[i] = 0.0;
     }
-    for (int i = 0; i < M * M; ++i) h.jtj[i] = h.spec_jtj[i] = c.covar[i] = 0.0;
+    for (int i = 0; i < M * M; ++i) h.jtj[i] = cool.spec_jtj[i] = c.covar[i] = 0.0;
     for (int i = 0; i < kInfoSz; ++i) c.info[i] = 0.0;
-    clear_req(h);
+    clear_req(h, req);
     if (c.n < M) {  // lm_core.c:502-505
       h.phase = D_DONE;
-      h.req.kind = RQ_DONE;
+      req.kind = RQ_DONE;
       return;
     }
-    h.req.kind = RQ_DIF_INIT;
-    for (int i = 0; i < M; ++i) h.req.p[i] = h.p[i];
+    req.kind = RQ_DIF_INIT;
+    for (int i = 0; i < M; ++i) req.p[i] = h.p[i];
     h.phase = D_INIT_EVAL;
   }
 
-  static LM_HD void clear_req(Hot &h) {
-    h.req.kind = RQ_DONE;
-    h.req.central = 0;
-    h.req.sel_hx = h.sel_hx;
-    h.req.sel_j = h.sel_j;
-    h.req.aux = 0;
-    h.req.dp_l2 = 0.0;
-    h.req.scal = 1.0;
-    for (int i = 0; i < M; ++i) h.req.p[i] = h.req.d[i] = h.req.q[i] = h.req.dp[i] = 0.0;
+  static LM_HD void clear_req(const Core &h, Request<M> &req) {
+    req.kind = RQ_DONE;
+    req.central = 0;
+    req.sel_hx = h.sel_hx;
+    req.sel_j = h.sel_j;
+    req.aux = 0;
+    req.dp_l2 = 0.0;
+    req.scal = 1.0;
+    for (int i = 0; i < M; ++i) req.p[i] = req.d[i] = req.q[i] = req.dp[i] = 0.0;
   }
 
-  static LM_HD void gradient_stats(Hot &h) {  // lm_core.c:657-662
+  static LM_HD void gradient_stats(Core &h, Cool &cool) {  // lm_core.c:657-662
     h.p_l2 = h.jte_inf = 0.0;
     for (int i = 0; i < M; ++i) {
       const double t = lm_abs(h.jte[i]);
       if (h.jte_inf < t) h.jte_inf = t;
-      h.diag[i] = h.jtj[i * M + i];
+      cool.diag[i] = h.jtj[i * M + i];
       h.p_l2 += h.p[i] * h.p[i];
     }
   }
 
   // ONE_LANE: the caller guarantees that exactly one lane of the wave executes this step (see lm_uniform)
   template <bool ONE_LANE = false>
-  LM_HD void step(const double *s, double maxabs) { run<ONE_LANE>(c, h, s, maxabs); }
+  LM_HD void step(const double *s, double maxabs) { run<ONE_LANE>(c, h, h.cool, h.req, s, maxabs); }
 
   template <bool ONE_LANE>
-  static LM_HD void run(Cold &c, Hot &h, const double *s, double /*maxabs*/) {
+  static LM_HD void run(Cold &c, Core &h, Cool &cool, Request<M> &req, const double *s, double /*maxabs*/) {
     int ph = ONE_LANE ? lm_uniform(h.phase) : h.phase;  // scalar register: phase transitions become scalar jumps
     LM_STAMP(0);
     for (;;) {
@@ -392,7 +420,7 @@ struct DifMachine {
       case D_INIT_EVAL:  // lm_core.c:551-564
         h.nfev = 1;
         h.p_e2 = s[0];
-        h.init_e2 = h.p_e2;
+        cool.init_e2 = h.p_e2;
         if (!lm_finite(h.p_e2)) h.stop = 7;
         h.nu = 20;
         ph = D_ITER_TOP;
@@ -409,11 +437,11 @@ struct DifMachine {
           break;
         }
         if ((h.updp && h.nu > 16) || h.updjac == c.refresh) {  // fresh FD Jacobian, lm_core.c:578-588
-          clear_req(h);
-          h.req.kind = RQ_DIF_JAC;
-          h.req.central = !c.o.forward;
-          for (int i = 0; i < M; ++i) h.req.p[i] = h.p[i];
-          fd_steps<M>(h.p, c.o.delta, h.req.d);
+          clear_req(h, req);
+          req.kind = RQ_DIF_JAC;
+          req.central = !c.o.forward;
+          for (int i = 0; i < M; ++i) req.p[i] = h.p[i];
+          fd_steps<M>(h.p, c.o.delta, req.d);
           ++h.njap;
           h.nfev += c.o.forward ? M : 2 * M;
           h.nu = 2;
@@ -430,16 +458,16 @@ struct DifMachine {
         unpack_lower<M>(s, h.jtj);
         for (int i = 0; i < M; ++i) h.jte[i] = s[SumLayout<M>::NL + i];
         h.newjac = 0;
-        gradient_stats(h);
+        gradient_stats(h, cool);
         ph = D_SOLVE;
         break;
 
       case D_GRADIENT:
         if (h.newjac) {  // lm_core.c:590-664 with the sums the trial pass produced for the updated J
           h.newjac = 0;
-          for (int i = 0; i < M * M; ++i) h.jtj[i] = h.spec_jtj[i];
-          for (int i = 0; i < M; ++i) h.jte[i] = h.spec_jte[i];
-          gradient_stats(h);
+          for (int i = 0; i < M * M; ++i) h.jtj[i] = cool.spec_jtj[i];
+          for (int i = 0; i < M; ++i) h.jte[i] = cool.spec_jte[i];
+          gradient_stats(h, cool);
         }
         ph = D_SOLVE;
         break;
@@ -455,7 +483,7 @@ struct DifMachine {
         if (h.k == 0) {  // lm_core.c:683-687
           double t = -DBL_MAX;
           for (int i = 0; i < M; ++i)
-            if (h.diag[i] > t) t = h.diag[i];
+            if (cool.diag[i] > t) t = cool.diag[i];
           h.mu = c.o.tau * t;
         }
         for (int i = 0; i < M; ++i) h.jtj[i * M + i] += h.mu;
@@ -469,7 +497,7 @@ struct DifMachine {
         h.dp_l2 = 0.0;
         for (int i = 0; i < M; ++i) {
           const double t = h.dp[i];
-          h.pdp[i] = h.p[i] + t;
+          cool.pdp[i] = h.p[i] + t;
           h.dp_l2 += t * t;
         }
         if (h.dp_l2 <= c.o.eps2sq * h.p_l2) {
@@ -482,14 +510,14 @@ struct DifMachine {
           ph = D_FINISH;
           break;
         }
-        clear_req(h);
-        h.req.kind = RQ_DIF_TRIAL;
+        clear_req(h, req);
+        req.kind = RQ_DIF_TRIAL;
         for (int i = 0; i < M; ++i) {
-          h.req.p[i] = h.p[i];
-          h.req.q[i] = h.pdp[i];
-          h.req.dp[i] = h.dp[i];
+          req.p[i] = h.p[i];
+          req.q[i] = cool.pdp[i];
+          req.dp[i] = h.dp[i];
         }
-        h.req.dp_l2 = h.dp_l2;
+        req.dp_l2 = h.dp_l2;
         ++h.nfev;
         ph = D_AFTER_TRIAL;
         LM_STAMP(4);
@@ -520,19 +548,19 @@ struct DifMachine {
                                 // residual that stays live -- they replace jtj/jte at the top of the next
                                 // iteration, as in the reference
             h.sel_j ^= 1;
-            unpack_lower<M>(s + 1, h.spec_jtj);
+            unpack_lower<M>(s + 1, cool.spec_jtj);
             const double *g = s + 1 + SumLayout<M>::NL + (h.accepted ? 0 : M);
-            for (int i = 0; i < M; ++i) h.spec_jte[i] = g[i];
+            for (int i = 0; i < M; ++i) cool.spec_jte[i] = g[i];
           } else {
-            clear_req(h);
-            h.req.kind = RQ_DIF_UPDATE;
-            h.req.aux = h.accepted;
+            clear_req(h, req);
+            req.kind = RQ_DIF_UPDATE;
+            req.aux = h.accepted;
             for (int i = 0; i < M; ++i) {
-              h.req.p[i] = h.p[i];
-              h.req.q[i] = h.pdp[i];
-              h.req.dp[i] = h.dp[i];
+              req.p[i] = h.p[i];
+              req.q[i] = cool.pdp[i];
+              req.dp[i] = h.dp[i];
             }
-            h.req.dp_l2 = h.dp_l2;
+            req.dp_l2 = h.dp_l2;
             ph = D_AFTER_UPDATE;
             { h.phase = ph; return; }
           }
@@ -543,15 +571,15 @@ struct DifMachine {
       }
 
       case D_AFTER_UPDATE:
-        unpack_lower<M>(s, h.spec_jtj);
-        for (int i = 0; i < M; ++i) h.spec_jte[i] = s[SumLayout<M>::NL + i];
+        unpack_lower<M>(s, cool.spec_jtj);
+        for (int i = 0; i < M; ++i) cool.spec_jte[i] = s[SumLayout<M>::NL + i];
         ph = D_DECIDE;
         break;
 
       case D_DECIDE:
         if (h.accepted) {
           h.nu = 2;
-          for (int i = 0; i < M; ++i) h.p[i] = h.pdp[i];
+          for (int i = 0; i < M; ++i) h.p[i] = cool.pdp[i];
           if (c.speculative) h.sel_hx ^= 1;  // e, hx <- trial values
           h.p_e2 = h.pdp_e2;
           h.updp = 1;
@@ -571,7 +599,7 @@ struct DifMachine {
           break;
         }
         h.nu = nu2;
-        for (int i = 0; i < M; ++i) h.jtj[i * M + i] = h.diag[i];
+        for (int i = 0; i < M; ++i) h.jtj[i * M + i] = cool.diag[i];
         ++h.k;
         ph = D_ITER_TOP;
         break;
@@ -579,8 +607,8 @@ struct DifMachine {
 
       case D_FINISH: {  // lm_core.c:809-841
         if (h.k >= c.itmax) h.stop = 3;
-        for (int i = 0; i < M; ++i) h.jtj[i * M + i] = h.diag[i];
-        c.info[0] = h.init_e2;
+        for (int i = 0; i < M; ++i) h.jtj[i * M + i] = cool.diag[i];
+        c.info[0] = cool.init_e2;
         c.info[1] = h.p_e2;
         c.info[2] = h.jte_inf;
         c.info[3] = h.dp_l2;
@@ -595,13 +623,13 @@ struct DifMachine {
         c.info[9] = (double)h.nlss;
         if (c.want_covar) lu_covar<M>(h.jtj, c.covar, h.p_e2, c.n);
         c.ret = (h.stop != 4 && h.stop != 7) ? h.k : kLmError;
-        clear_req(h);
+        clear_req(h, req);
         ph = D_DONE;
         { h.phase = ph; return; }
       }
 
       default:
-        h.req.kind = RQ_DONE;
+        req.kind = RQ_DONE;
         { h.phase = ph; return; }
       }
     }
@@ -636,17 +664,42 @@ struct BcMachine {
     double info[kInfoSz], covar[M * M];
     int ret;
   };
-  struct Hot {
+  struct Core {  // everything an LM step reads or writes, except the request it leaves
     int phase, k, stop, nu, nfev, njev, nlss, gprev;
-    double p[M], mu, p_e2, init_e2, jte_inf, p_l2, dp_l2, pdp_e2, keep_max;
-    double jtj[M * M], jte[M], diag[M], dp[M], pdp[M];
-    double t, t0, gdp;
-    // line-search locals (lmbc_core.c:218-225)
-    double ls_f0, ls_lambda, ls_plmbda, ls_pfpls, ls_tlmbda, ls_rmnlmb, ls_slp;
+    double p[M], mu, p_e2, jte_inf, p_l2, dp_l2, pdp_e2;
+    double jtj[M * M], jte[M], dp[M], pdp[M];
+    double t, gdp;
     int ls_first, ls_left;
     int pg_n, pg_single;  // candidates in flight; force the next projected-gradient request to a single candidate
+  };
+  struct Cool {  // the less busy half of the state (see Hot)
+    double init_e2, keep_max, diag[M], t0;
+    // line-search locals (lmbc_core.c:218-225)
+    double ls_f0, ls_lambda, ls_plmbda, ls_pfpls, ls_tlmbda, ls_rmnlmb, ls_slp;
+  };
+  // Core + Cool + the request.  run() takes them separately, so that a kernel can step on a REGISTER copy of Core
+  // while the rest stays in LDS (resident_fit.hip: the sweeping waves read the request there; with Cool in registers as
+  // well, hipcc spilled ~100 VGPRs of the step to scratch, which cost more than the LDS round trips it saved)
+  struct Hot : Core {
+    Cool cool;
     Request<M> req;
   };
+  // where ONE machine is stepped by a whole wave (every lane the same values): moves the counters and flags of a
+  // register copy into scalar registers, so that the step's integer logic and branches run on the scalar unit
+  static LM_HD void uniform_ints(Core &h) {
+    h.phase = lm_uniform(h.phase);
+    h.k = lm_uniform(h.k);
+    h.stop = lm_uniform(h.stop);
+    h.nu = lm_uniform(h.nu);
+    h.nfev = lm_uniform(h.nfev);
+    h.njev = lm_uniform(h.njev);
+    h.nlss = lm_uniform(h.nlss);
+    h.gprev = lm_uniform(h.gprev);
+    h.ls_first = lm_uniform(h.ls_first);
+    h.ls_left = lm_uniform(h.ls_left);
+    h.pg_n = lm_uniform(h.pg_n);
+    h.pg_single = lm_uniform(h.pg_single);
+  }
   Cold c;
   Hot h;
 
@@ -673,29 +726,31 @@ struct BcMachine {
       }
     }
   }
-  static LM_HD void clear_req(Hot &h) {
-    h.req.kind = RQ_DONE;
-    h.req.central = 0;
-    h.req.sel_hx = h.req.sel_j = h.req.aux = 0;
-    h.req.dp_l2 = 0.0;
-    h.req.scal = 1.0;
-    for (int i = 0; i < M; ++i) h.req.p[i] = h.req.d[i] = h.req.q[i] = h.req.dp[i] = 0.0;
+  static LM_HD void clear_req(const Core &h, Request<M> &req) {
+    req.kind = RQ_DONE;
+    req.central = 0;
+    req.sel_hx = req.sel_j = req.aux = 0;
+    req.dp_l2 = 0.0;
+    req.scal = 1.0;
+    for (int i = 0; i < M; ++i) req.p[i] = req.d[i] = req.q[i] = req.dp[i] = 0.0;
   }
   // ask for ||x - f(v)||^2 where v lives in the (possibly scaled) search space.  Only the fields an
   // evaluation pass reads are written (kind, p, scal); v is a local array.
-  static LM_HD void request_eval(const Cold &c, Hot &h, const double *v, int kind = RQ_EVAL) {
-    h.req.kind = kind;
-    h.req.scal = 1.0;
+  static LM_HD void request_eval(const Cold &c, Core &h, Request<M> &req, const double *v, int kind = RQ_EVAL) {
+    req.kind = kind;
+    req.scal = 1.0;
     if (c.has_dscl) {
-      for (int i = 0; i < M; ++i) h.req.p[i] = v[i] * c.dscl[i];
+      for (int i = 0; i < M; ++i) req.p[i] = v[i] * c.dscl[i];
     } else {
-      for (int i = 0; i < M; ++i) h.req.p[i] = v[i];
+      for (int i = 0; i < M; ++i) req.p[i] = v[i];
     }
     ++h.nfev;
   }
 
   LM_HD void start(const double *p0, int n_, const double *lb_, const double *ub_, const double *dscl_,
                    int itmax_, const double *opts, int want_covar_, int multi_ = 1) {
+    Request<M> &req = h.req;
+    Cool &cool = h.cool;
     c.multi = (multi_ < 1) ? 1 : ((multi_ > kMaxCand) ? kMaxCand : multi_);
     h.pg_n = h.pg_single = 0;
     c.o = make_options(opts);
@@ -717,10 +772,10 @@ struct BcMachine {
     h.gprev = 0;
     c.infeasible_mask = 0;
     c.bad_input = 0;
-    h.mu = h.jte_inf = h.p_l2 = h.t = h.t0 = h.gdp = 0.0;
-    h.p_e2 = h.init_e2 = h.pdp_e2 = h.keep_max = 0.0;
+    h.mu = h.jte_inf = h.p_l2 = h.t = cool.t0 = h.gdp = 0.0;
+    h.p_e2 = cool.init_e2 = h.pdp_e2 = cool.keep_max = 0.0;
     h.dp_l2 = DBL_MAX;
-    h.ls_f0 = h.ls_lambda = h.ls_plmbda = h.ls_pfpls = h.ls_tlmbda = h.ls_rmnlmb = h.ls_slp = 0.0;
+    cool.ls_f0 = cool.ls_lambda = cool.ls_plmbda = cool.ls_pfpls = cool.ls_tlmbda = cool.ls_rmnlmb = cool.ls_slp = 0.0;
     h.ls_first = 1;
     h.ls_left = 0;
     c.ret = kLmError;
@@ -729,11 +784,11 @@ struct BcMachine {
       c.lb[i] = c.has_lb ? lb_[i] : -DBL_MAX;
       c.ub[i] = c.has_ub ? ub_[i] : DBL_MAX;
       c.dscl[i] = c.has_dscl ? dscl_[i] : 1.0;
-      h.jte[i] = h.diag[i] = h.dp[i] = h.pdp[i] = 0.0;
+      h.jte[i] = cool.diag[i] = h.dp[i] = h.pdp[i] = 0.0;
     }
     for (int i = 0; i < M * M; ++i) h.jtj[i] = c.covar[i] = 0.0;
     for (int i = 0; i < kInfoSz; ++i) c.info[i] = 0.0;
-    clear_req(h);
+    clear_req(h, req);
     h.phase = B_DONE;
     if (c.n < M) {  // lmbc_core.c:440-443
       c.bad_input = 1;
@@ -755,13 +810,13 @@ struct BcMachine {
     project(c, h.p);  // lmbc_core.c:514-520; the stderr warning is printed by the host shim from the mask
     for (int i = 0; i < M; ++i)
       if (c.p_start[i] != h.p[i]) c.infeasible_mask |= (1 << i);
-    clear_req(h);
-    h.req.kind = RQ_EVAL;  // the first evaluation is at the unscaled projected start, lmbc_core.c:523
-    for (int i = 0; i < M; ++i) h.req.p[i] = h.p[i];
+    clear_req(h, req);
+    req.kind = RQ_EVAL;  // the first evaluation is at the unscaled projected start, lmbc_core.c:523
+    for (int i = 0; i < M; ++i) req.p[i] = h.p[i];
     h.phase = B_INIT_EVAL;
   }
 
-  static LM_HD void accept_trial(Hot &h) {  // p <- pdp, ||e||^2 <- trial value
+  static LM_HD void accept_trial(Core &h) {  // p <- pdp, ||e||^2 <- trial value
     for (int i = 0; i < M; ++i) h.p[i] = h.pdp[i];
     h.p_e2 = h.pdp_e2;
   }
@@ -771,10 +826,10 @@ struct BcMachine {
   // prologue (pow, square roots, divisions) and B_FINISH -- only run when `heavy` is set; otherwise the step stops in front
   // of them with RQ_YIELD.  Pure scheduling: a machine's trajectory does not depend on when its phases run.
   template <bool ONE_LANE = false, bool MULTI = true, bool GATED = false>
-  LM_HD void step(const double *s, double maxabs, bool heavy = true) { run<ONE_LANE, MULTI, GATED>(c, h, s, maxabs, heavy); }
+  LM_HD void step(const double *s, double maxabs, bool heavy = true) { run<ONE_LANE, MULTI, GATED>(c, h, h.cool, h.req, s, maxabs, heavy); }
 
   template <bool ONE_LANE, bool MULTI, bool GATED>
-  static LM_HD void run(Cold &c, Hot &h, const double *s, double maxabs, bool heavy) {
+  static LM_HD void run(Cold &c, Core &h, Cool &cool, Request<M> &req, const double *s, double maxabs, bool heavy) {
     constexpr double alpha = 1e-4, beta = 0.9, gamma = 0.99995, rho = 1e-8, tming = 1e-18, tini = 1.0;
     int ph = ONE_LANE ? lm_uniform(h.phase) : h.phase;  // scalar register: phase transitions become scalar jumps
     for (;;) {
@@ -786,13 +841,13 @@ struct BcMachine {
       // trips per step, i.e. the expensive bodies (LU, line-search interpolation, pow) would run several times per step.
       // `break` inside a block leaves the block (do { } while (0)), exactly as it left the switch before.
       if (ph <= 0 || ph >= B_DONE) {
-        h.req.kind = RQ_DONE;
+        req.kind = RQ_DONE;
         { h.phase = ph; return; }
       }
       LM_PHASE(B_INIT_EVAL) {  // lmbc_core.c:523-540
         h.nfev = 1;
         h.p_e2 = s[0];
-        h.init_e2 = h.p_e2;
+        cool.init_e2 = h.p_e2;
         if (!lm_finite(h.p_e2)) h.stop = 7;
         if (c.has_dscl)
           for (int i = M; i-- > 0;) {
@@ -828,7 +883,7 @@ struct BcMachine {
             const double a = lm_abs(h.jte[i]);
             if (h.jte_inf < a) h.jte_inf = a;
           }
-          h.diag[i] = h.jtj[i * M + i];
+          cool.diag[i] = h.jtj[i * M + i];
           h.p_l2 += h.p[i] * h.p[i];
         }
         if (satisfied == nactive && (h.jte_inf <= c.o.eps1)) {
@@ -841,7 +896,7 @@ struct BcMachine {
           if (!c.has_lb && !c.has_ub) {
             double m0 = -DBL_MAX;
             for (int i = 0; i < M; ++i)
-              if (h.diag[i] > m0) m0 = h.diag[i];
+              if (cool.diag[i] > m0) m0 = cool.diag[i];
             h.mu = c.o.tau * m0;
           } else
             h.mu = 0.5 * c.o.tau * h.p_e2;  // Kanzow's starting damping
@@ -865,7 +920,7 @@ struct BcMachine {
             break;
           }
           h.nu = nu2;
-          for (int i = 0; i < M; ++i) h.jtj[i * M + i] = h.diag[i];
+          for (int i = 0; i < M; ++i) h.jtj[i * M + i] = cool.diag[i];
           break;  // solve again
         }
         double pc[M], v[M], l2 = 0.0;
@@ -892,7 +947,7 @@ struct BcMachine {
           ph = B_END_ITER;
           break;
         }
-        request_eval(c, h, v);
+        request_eval(c, h, req, v);
         ph = B_AFTER_LM_EVAL;
         { h.phase = ph; return; }
       } LM_PHASE_END
@@ -905,10 +960,10 @@ struct BcMachine {
             ph = B_END_ITER;
             break;
           }
-          h.keep_max = maxabs;
-          request_eval(c, h, h.pdp, RQ_SCALED);
+          cool.keep_max = maxabs;
+          request_eval(c, h, req, h.pdp, RQ_SCALED);
           --h.nfev;  // not a user-visible function evaluation
-          h.req.scal = maxabs;
+          req.scal = maxabs;
           ph = B_AFTER_LM_NORM;
           { h.phase = ph; return; }
         }
@@ -917,7 +972,7 @@ struct BcMachine {
       } LM_PHASE_END
 
       LM_PHASE(B_AFTER_LM_NORM) {
-        if (!lm_finite(h.keep_max * sqrt(s[0]))) {
+        if (!lm_finite(cool.keep_max * sqrt(s[0]))) {
           h.stop = 7;
           ph = B_END_ITER;
           break;
@@ -965,7 +1020,7 @@ struct BcMachine {
         const double steptl = 1e3 * sqrt(DBL_EPSILON);
         double pn = sqrt(h.p_l2);
         const double stepmx = 1e3 * ((pn >= 1.0) ? pn : 1.0);
-        h.ls_f0 = h.p_e2 * 0.5;
+        cool.ls_f0 = h.p_e2 * 0.5;
         double acc = 0.0;
         for (int i = M; i-- > 0;) acc += h.dp[i] * h.dp[i];
         double sln = sqrt(acc);
@@ -975,17 +1030,17 @@ struct BcMachine {
           sln = stepmx;
         }
         double rln = 0.0;
-        h.ls_slp = 0.0;
+        cool.ls_slp = 0.0;
         for (int i = M; i-- > 0;) {
-          h.ls_slp += h.jte[i] * h.dp[i];
+          cool.ls_slp += h.jte[i] * h.dp[i];
           const double den = (lm_abs(h.p[i]) >= 1.0) ? lm_abs(h.p[i]) : 1.0;
           const double rel = lm_abs(h.dp[i]) / den;
           if (rln < rel) rln = rel;
         }
-        h.ls_rmnlmb = steptl / rln;
-        h.ls_lambda = 1.0;
+        cool.ls_rmnlmb = steptl / rln;
+        cool.ls_lambda = 1.0;
         h.ls_first = 1;
-        h.ls_plmbda = h.ls_pfpls = h.ls_tlmbda = 0.0;
+        cool.ls_plmbda = cool.ls_pfpls = cool.ls_tlmbda = 0.0;
         h.ls_left = kLsItMax;
         ph = B_LS_ISSUE;
         break;
@@ -994,7 +1049,7 @@ struct BcMachine {
       LM_PHASE(B_LS_EVAL) {  // lmbc_core.c:269-332
         const double fpls = 0.5 * s[0];
         h.pdp_e2 = s[0];
-        if (fpls <= h.ls_f0 + h.ls_slp * alpha * h.ls_lambda) {  // satisfactory point
+        if (fpls <= cool.ls_f0 + cool.ls_slp * alpha * cool.ls_lambda) {  // satisfactory point
           if (!lm_finite(h.pdp_e2)) {  // lmbc_core.c:828
             ph = B_PG_BEGIN;
             break;
@@ -1003,36 +1058,36 @@ struct BcMachine {
           ph = B_COMMIT;
           break;
         }
-        if (h.ls_lambda < h.ls_rmnlmb) {
+        if (cool.ls_lambda < cool.ls_rmnlmb) {
           ph = B_PG_BEGIN;
           break;
         }
         if (!lm_finite(fpls)) {
-          h.ls_lambda *= 0.1;
+          cool.ls_lambda *= 0.1;
           h.ls_first = 1;
         } else {
           if (h.ls_first) {
-            h.ls_tlmbda = -h.ls_lambda * h.ls_slp / ((fpls - h.ls_f0 - h.ls_slp) * 2.0);
+            cool.ls_tlmbda = -cool.ls_lambda * cool.ls_slp / ((fpls - cool.ls_f0 - cool.ls_slp) * 2.0);
             h.ls_first = 0;
           } else {
-            const double t1 = fpls - h.ls_f0 - h.ls_lambda * h.ls_slp;
-            const double t2 = h.ls_pfpls - h.ls_f0 - h.ls_plmbda * h.ls_slp;
-            const double t3 = 1.0 / (h.ls_lambda - h.ls_plmbda);
-            const double a3 = 3.0 * t3 * (t1 / (h.ls_lambda * h.ls_lambda) - t2 / (h.ls_plmbda * h.ls_plmbda));
-            const double b = t3 * (t2 * h.ls_lambda / (h.ls_plmbda * h.ls_plmbda) - t1 * h.ls_plmbda / (h.ls_lambda * h.ls_lambda));
-            const double disc = b * b - a3 * h.ls_slp;
+            const double t1 = fpls - cool.ls_f0 - cool.ls_lambda * cool.ls_slp;
+            const double t2 = cool.ls_pfpls - cool.ls_f0 - cool.ls_plmbda * cool.ls_slp;
+            const double t3 = 1.0 / (cool.ls_lambda - cool.ls_plmbda);
+            const double a3 = 3.0 * t3 * (t1 / (cool.ls_lambda * cool.ls_lambda) - t2 / (cool.ls_plmbda * cool.ls_plmbda));
+            const double b = t3 * (t2 * cool.ls_lambda / (cool.ls_plmbda * cool.ls_plmbda) - t1 * cool.ls_plmbda / (cool.ls_lambda * cool.ls_lambda));
+            const double disc = b * b - a3 * cool.ls_slp;
             if (disc > b * b)
-              h.ls_tlmbda = (-b + ((a3 < 0) ? -sqrt(disc) : sqrt(disc))) / a3;
+              cool.ls_tlmbda = (-b + ((a3 < 0) ? -sqrt(disc) : sqrt(disc))) / a3;
             else
-              h.ls_tlmbda = (-b + ((a3 < 0) ? sqrt(disc) : -sqrt(disc))) / a3;
-            if (h.ls_tlmbda > h.ls_lambda * 0.5) h.ls_tlmbda = h.ls_lambda * 0.5;
+              cool.ls_tlmbda = (-b + ((a3 < 0) ? sqrt(disc) : -sqrt(disc))) / a3;
+            if (cool.ls_tlmbda > cool.ls_lambda * 0.5) cool.ls_tlmbda = cool.ls_lambda * 0.5;
           }
-          h.ls_plmbda = h.ls_lambda;
-          h.ls_pfpls = fpls;
-          if (h.ls_tlmbda < h.ls_lambda * 0.1)
-            h.ls_lambda *= 0.1;
+          cool.ls_plmbda = cool.ls_lambda;
+          cool.ls_pfpls = fpls;
+          if (cool.ls_tlmbda < cool.ls_lambda * 0.1)
+            cool.ls_lambda *= 0.1;
           else
-            h.ls_lambda = h.ls_tlmbda;
+            cool.ls_lambda = cool.ls_tlmbda;
         }
         ph = B_LS_ISSUE;
         break;
@@ -1044,20 +1099,20 @@ struct BcMachine {
           break;
         }
         double v[M];
-        const double lam = h.ls_lambda;
+        const double lam = cool.ls_lambda;
         for (int i = M; i-- > 0;) v[i] = h.p[i] + lam * h.dp[i];
         project(c, v);
-        h.req.kind = RQ_EVAL;
-        h.req.scal = 1.0;
+        req.kind = RQ_EVAL;
+        req.scal = 1.0;
         if (!c.has_dscl) {
           for (int i = 0; i < M; ++i) {
-            h.req.p[i] = v[i];
+            req.p[i] = v[i];
             h.pdp[i] = v[i];
           }
         } else {  // the reference multiplies and divides xpls in place, lmbc_core.c:263-265
           for (int i = M; i-- > 0;) {
             v[i] *= c.dscl[i];
-            h.req.p[i] = v[i];
+            req.p[i] = v[i];
             v[i] /= c.dscl[i];
             h.pdp[i] = v[i];
           }
@@ -1075,12 +1130,12 @@ struct BcMachine {
             ph = B_FINISH;
             break;
           }
-          h.keep_max = maxabs;
+          cool.keep_max = maxabs;
           double v[M];
           for (int i = 0; i < M; ++i) v[i] = h.pdp[i];
-          request_eval(c, h, v, RQ_SCALED);
+          request_eval(c, h, req, v, RQ_SCALED);
           --h.nfev;
-          h.req.scal = maxabs;
+          req.scal = maxabs;
           ph = B_PG_NORM;
           { h.phase = ph; return; }
         }
@@ -1089,7 +1144,7 @@ struct BcMachine {
       } LM_PHASE_END
 
       LM_PHASE(B_PG_NORM) {
-        if (!lm_finite(h.keep_max * sqrt(s[0]))) {
+        if (!lm_finite(cool.keep_max * sqrt(s[0]))) {
           h.stop = 7;
           ph = B_FINISH;  // "goto breaknested": k is not advanced
           break;
@@ -1133,7 +1188,7 @@ struct BcMachine {
           h.pdp_e2 = fnew;
           h.gdp = gd;
           if (h.gprev && fnew <= fold + 2.0 * 0.99999 * gd) {  // remembered t was too small
-            tt = h.t0;
+            tt = cool.t0;
             h.gprev = 0;
             tt *= beta;
             break;
@@ -1156,7 +1211,7 @@ struct BcMachine {
         h.gdp = g;
         const double fnew = h.pdp_e2, fold = h.p_e2;
         if (h.gprev && fnew <= fold + 2.0 * 0.99999 * g) {  // remembered t was too small
-          double tt = h.t0;
+          double tt = cool.t0;
           h.gprev = 0;
           tt *= beta;  // the reference's `continue` still runs the loop increment
           h.t = tt;
@@ -1178,8 +1233,8 @@ struct BcMachine {
         for (int i = 0; i < M; ++i) g2 += h.jte[i] * h.jte[i];
         g2 = sqrt(g2);
         g2 = 100.0 / (1.0 + g2);
-        h.t0 = (g2 <= tini) ? g2 : tini;
-        h.t = h.gprev ? h.t : h.t0;
+        cool.t0 = (g2 <= tini) ? g2 : tini;
+        h.t = h.gprev ? h.t : cool.t0;
         ph = B_PG_ISSUE;
         break;
       } LM_PHASE_END
@@ -1207,7 +1262,7 @@ struct BcMachine {
           project(c, v);
           for (int i = 0; i < M; ++i) {
             if (j == 0) v0[i] = v[i];
-            h.req.pk[j][i] = c.has_dscl ? v[i] * c.dscl[i] : v[i];
+            req.pk[j][i] = c.has_dscl ? v[i] * c.dscl[i] : v[i];
           }
           ++cnt;
           tt *= beta;
@@ -1221,14 +1276,14 @@ struct BcMachine {
             l2 += d * d;
           }
           h.dp_l2 = l2;
-          request_eval(c, h, v0);
+          request_eval(c, h, req, v0);
           ph = B_PG_EVAL;
           { h.phase = ph; return; }
         }
         h.pg_n = cnt;
-        h.req.kind = RQ_EVAL_MULTI;
-        h.req.nk = cnt;
-        h.req.scal = 1.0;
+        req.kind = RQ_EVAL_MULTI;
+        req.nk = cnt;
+        req.scal = 1.0;
         ph = B_PG_MULTI;
         { h.phase = ph; return; }
       } LM_PHASE_END
@@ -1265,11 +1320,11 @@ struct BcMachine {
           ph = B_FINISH;
           break;
         }
-        clear_req(h);  // FD Jacobian at the unscaled point, lmbc_core.c:555-561 + :1043-1054
-        h.req.kind = RQ_JAC;
-        h.req.central = !c.o.forward;
-        for (int i = 0; i < M; ++i) h.req.p[i] = c.has_dscl ? h.p[i] * c.dscl[i] : h.p[i];
-        fd_steps<M>(h.req.p, c.o.delta, h.req.d);
+        clear_req(h, req);  // FD Jacobian at the unscaled point, lmbc_core.c:555-561 + :1043-1054
+        req.kind = RQ_JAC;
+        req.central = !c.o.forward;
+        for (int i = 0; i < M; ++i) req.p[i] = c.has_dscl ? h.p[i] * c.dscl[i] : h.p[i];
+        fd_steps<M>(req.p, c.o.delta, req.d);
         ++h.njev;
         ph = B_AFTER_JAC;
         { h.phase = ph; return; }
@@ -1279,8 +1334,8 @@ struct BcMachine {
       if (!GATED || heavy)
       LM_PHASE(B_FINISH) {  // lmbc_core.c:973-1021, :1119-1124
         if (h.k >= c.itmax) h.stop = 3;
-        for (int i = 0; i < M; ++i) h.jtj[i * M + i] = h.diag[i];
-        c.info[0] = h.init_e2;
+        for (int i = 0; i < M; ++i) h.jtj[i * M + i] = cool.diag[i];
+        c.info[0] = cool.init_e2;
         c.info[1] = h.p_e2;
         c.info[2] = h.jte_inf;
         c.info[3] = h.dp_l2;
@@ -1302,7 +1357,7 @@ struct BcMachine {
         if (c.has_dscl)
           for (int i = 0; i < M; ++i) h.p[i] *= c.dscl[i];
         c.ret = (h.stop != 4 && h.stop != 7) ? h.k : kLmError;
-        clear_req(h);
+        clear_req(h, req);
         ph = B_DONE;
         { h.phase = ph; return; }
       } LM_PHASE_END
@@ -1324,25 +1379,42 @@ struct DerMachine {
     double info[kInfoSz], covar[M * M];
     int ret;
   };
-  struct Hot {
+  struct Core {  // everything an LM step reads or writes, except the request it leaves
     int phase, k, stop, nu, nfev, njev, nlss;
     double p[M], mu, p_e2, init_e2, jte_inf, p_l2, dp_l2, pdp_e2;
     double jtj[M * M], jte[M], diag[M], dp[M], pdp[M];
+  };
+  // Core + Cool + the request.  run() takes them separately, so that a kernel can step on a REGISTER copy of Core
+  // while the rest stays in LDS (resident_fit.hip: the sweeping waves read the request there; with Cool in registers as
+  // well, hipcc spilled ~100 VGPRs of the step to scratch, which cost more than the LDS round trips it saved)
+  struct Hot : Core {
     Request<M> req;
   };
+  // where ONE machine is stepped by a whole wave (every lane the same values): moves the counters and flags of a
+  // register copy into scalar registers, so that the step's integer logic and branches run on the scalar unit
+  static LM_HD void uniform_ints(Core &h) {
+    h.phase = lm_uniform(h.phase);
+    h.k = lm_uniform(h.k);
+    h.stop = lm_uniform(h.stop);
+    h.nu = lm_uniform(h.nu);
+    h.nfev = lm_uniform(h.nfev);
+    h.njev = lm_uniform(h.njev);
+    h.nlss = lm_uniform(h.nlss);
+  }
   Cold c;
   Hot h;
 
-  static LM_HD void clear_req(Hot &h) {
-    h.req.kind = RQ_DONE;
-    h.req.central = 0;
-    h.req.sel_hx = h.req.sel_j = h.req.aux = 0;
-    h.req.dp_l2 = 0.0;
-    h.req.scal = 1.0;
-    for (int i = 0; i < M; ++i) h.req.p[i] = h.req.d[i] = h.req.q[i] = h.req.dp[i] = 0.0;
+  static LM_HD void clear_req(const Core &h, Request<M> &req) {
+    req.kind = RQ_DONE;
+    req.central = 0;
+    req.sel_hx = req.sel_j = req.aux = 0;
+    req.dp_l2 = 0.0;
+    req.scal = 1.0;
+    for (int i = 0; i < M; ++i) req.p[i] = req.d[i] = req.q[i] = req.dp[i] = 0.0;
   }
 
   LM_HD void start(const double *p0, int n_, int itmax_, const double *opts, int want_covar_) {
+    Request<M> &req = h.req;
     c.o = make_options(opts);
     c.itmax = itmax_;
     c.n = n_;
@@ -1359,18 +1431,21 @@ struct DerMachine {
     }
     for (int i = 0; i < M * M; ++i) h.jtj[i] = c.covar[i] = 0.0;
     for (int i = 0; i < kInfoSz; ++i) c.info[i] = 0.0;
-    clear_req(h);
+    clear_req(h, req);
     if (c.n < M) {  // lm_core.c:121-124
       h.phase = R_DONE;
       return;
     }
-    h.req.kind = RQ_EVAL;
-    for (int i = 0; i < M; ++i) h.req.p[i] = h.p[i];
+    req.kind = RQ_EVAL;
+    for (int i = 0; i < M; ++i) req.p[i] = h.p[i];
     h.phase = R_INIT_EVAL;
   }
 
   template <bool ONE_LANE = false>
-  LM_HD void step(const double *s, double /*maxabs*/) {
+  LM_HD void step(const double *s, double maxabs) { run<ONE_LANE>(c, h, h.req, s, maxabs); }
+
+  template <bool ONE_LANE>
+  static LM_HD void run(Cold &c, Core &h, Request<M> &req, const double *s, double /*maxabs*/) {
     int ph = ONE_LANE ? lm_uniform(h.phase) : h.phase;
     for (;;) {
       if (ONE_LANE) ph = lm_uniform(ph);  // re-assert uniformity: assignments under (formally) divergent branches lose it
@@ -1393,9 +1468,9 @@ struct DerMachine {
           ph = R_FINISH;
           break;
         }
-        clear_req(h);
-        h.req.kind = RQ_JAC;
-        for (int i = 0; i < M; ++i) h.req.p[i] = h.p[i];
+        clear_req(h, req);
+        req.kind = RQ_JAC;
+        for (int i = 0; i < M; ++i) req.p[i] = h.p[i];
         ++h.njev;
         ph = R_AFTER_JAC;
         h.phase = ph;
@@ -1448,9 +1523,9 @@ struct DerMachine {
             ph = R_END_ITER;
             break;
           }
-          clear_req(h);
-          h.req.kind = RQ_EVAL;
-          for (int i = 0; i < M; ++i) h.req.p[i] = h.pdp[i];
+          clear_req(h, req);
+          req.kind = RQ_EVAL;
+          for (int i = 0; i < M; ++i) req.p[i] = h.pdp[i];
           ++h.nfev;
           ph = R_AFTER_EVAL;
           h.phase = ph;
@@ -1529,14 +1604,14 @@ struct DerMachine {
         c.info[9] = (double)h.nlss;
         if (c.want_covar) lu_covar<M>(h.jtj, c.covar, h.p_e2, c.n);
         c.ret = (h.stop != 4 && h.stop != 7) ? h.k : kLmError;
-        clear_req(h);
+        clear_req(h, req);
         ph = R_DONE;
         h.phase = ph;
         return;
       }
 
       default:
-        h.req.kind = RQ_DONE;
+        req.kind = RQ_DONE;
         h.phase = ph;
         return;
       }

@@ -4,23 +4,33 @@
 // fit runs inside one launch of #CUs workgroups (one 512-thread workgroup per CU, all co-resident).  Every workgroup
 // reads its tile of the sample planes from HBM exactly once and keeps it for the rest of the fit:
 //
-//   waves 1..7, "sample waves"         per lane 10 samples in registers: c0, x, the two per-sample invariants
-//                                      (brdf_models.h: Prep) and, for dlevmar_dif, f(p) and f(p+Dp) (lm_core.c:551, :742)
-//   LDS (dlevmar_dif only, 105 KiB)    the secant Jacobian rows, three SoA planes            (lm_core.c:759-769)
-//   wave 0, "control wave"             no samples: it runs the exchange and the serial LM step, so the step's ~150
-//                                      live registers never compete with the resident samples (a symmetric
-//                                      eight-wave version spilled 40-120 VGPRs and lost to the launch chain)
+//   waves 1..7                         per lane 8 samples in registers: c0, x, the two per-sample invariants
+//                                      (brdf_models.h: Prep) and, for dlevmar_dif, f(p), f(p+Dp) (lm_core.c:551, :742)
+//                                      and the Broyden scalar of the last trial (lm_core.c:763)
+//   wave 0, "control wave"             the same 8 samples per lane, but parked in LDS (28 KiB): it sweeps them from
+//                                      there with a rolled loop, so that the ~250 live registers of the serial LM step it
+//                                      also runs never compete with resident samples -- and all four SIMDs carry the
+//                                      same sweep load (2 waves x 8 samples; the first version had seven sample waves
+//                                      x 10 samples and an idle control wave: 20 sample-iterations on three SIMDs, 10 on
+//                                      the fourth)
+//   LDS (dlevmar_dif only, 96 KiB)     the secant Jacobian rows, three SoA planes            (lm_core.c:759-769)
 //
 // A pass (= one LM evaluation: e=x-hx / ||e||^2, FD Jacobian, J^T J / J^T e, Broyden update, brdfdata.cpp:975-988 +
 // misc_core.c:153-171 + lm_core.c:617-653) therefore moves no sample bytes at all.  Passes are separated by an
 // in-launch exchange of the per-workgroup partial sums instead of a kernel boundary:
 //
-//   sample waves : sweep -> reduction over the seven waves -> <= 14 partial sums in LDS            (barriers X1, X2)
+//   all waves    : sweep -> reduction over the eight waves -> <= 14 partial sums in LDS            (barriers X1, X2)
 //   control wave : publishes them as tagged 8-byte granules {tag : 32, half of a double : 32}, each ONE write-through
 //                  (sc1) store; gathers everybody's in two levels (control_exchange below); folds in a fixed order;
 //                  steps ITS OWN copy of the LM state machine (lm_machine.h) -- the same redundant execution as in
-//                  the launch chain of stream_fit.hip, so there is no broadcast hop; builds the next pass's uniforms
-//                                                                                                       (barrier B)
+//                  the launch chain of stream_fit.hip, so there is no broadcast hop -- on a REGISTER copy of the
+//                  machine's hot half (every field access of the LDS-resident machine was a dependent LDS round
+//                  trip: 3.6 us per step); builds the next pass's uniforms                          (barrier B)
+//
+// The speculative dlevmar_dif protocol (lm_machine.h): a trial pass forms the Broyden-updated Jacobian row for the sums
+// only and keeps the update's scalar t = (f(p+Dp) - f(p) - J Dp)/||Dp||^2 per sample; if the machine adopts the update,
+// the NEXT trial pass applies J += t Dp^T on the fly while it reads the row anyway (the first version re-derived t in
+// a separate commit sweep: ~1 us per pass).
 //
 // The granules are recipe R2 of the CDNA guide (cdna_hip_programming.md, Guideline 16: "the data IS the flag"): a
 // granule is one naturally aligned 8-byte word written by one store, so it cannot tear; no flag, no fence, no ordering
@@ -42,14 +52,13 @@
 
 namespace brdf {
 
-constexpr int kRThreads = 512;               // wave 0 = control wave, waves 1..7 = sample waves
-constexpr int kRWorkers = kRThreads - kWave;  // 448 lanes hold samples
-constexpr int kRSpt = 10;                     // samples per worker lane (448 * 10 = 4480 >= 4096)
-constexpr int kRTile = 4096;                  // samples per workgroup (so that #CUs * kRTile >= 2^20 on MI355X)
-constexpr int kRCap = kRWorkers * kRSpt;      // sample slots per workgroup
+constexpr int kRThreads = 512;               // eight waves, all of them sweep; wave 0 is also the control wave
+constexpr int kRSpt = 8;                      // samples per lane
+constexpr int kRTile = kRThreads * kRSpt;     // 4096 samples per workgroup (so that #CUs * kRTile >= 2^20 on MI355X)
+constexpr int kRCap = kRTile;                 // sample slots per workgroup
 constexpr int kRowWords = 2 * kSlots;         // 8-byte granules per partial row: 2 per slot
-constexpr int kRowStride = 256;               // workgroups per granule word (>= #CUs), a whole number of lines
-constexpr int kRedCols = kRWorkers / 4;       // reduction buffer columns (after two in-row DPP steps)
+constexpr int kRowStride = 256;               // most workgroups of a launch (>= #CUs)
+constexpr int kRedCols = kRThreads / 4;       // reduction buffer columns (after two in-row DPP steps)
 constexpr long long kSpinBudgetTicks = 200000000LL;  // default budget per wait: 2 s of s_memrealtime (100 MHz)
 
 typedef unsigned long long u64;
@@ -62,8 +71,8 @@ struct ResidentCtl {  // zeroed before every launch (uploaded together with the 
 
 struct ResidentCtx {
   const double *c0, *c1, *c2, *x;
-  u64 *rows;            // [2][kRowWords][kRowStride] tagged granules; every tag stored so far is <= tag_base
-  u64 *groups;          // [2][kRowWords][kGroupStride]: sums over groups of 16 workgroups, same granule format
+  u64 *rows;            // [2][kMaxGroups][kRowWords][kGroup] tagged granules; every tag stored so far is <= tag_base
+  u64 *groups;          // [2][kReplicas][kRowWords][kMaxGroups]: sums over groups of 16 workgroups, same granule format
   ResidentCtl *ctl;
   const void *machine0;  // DifMachine<3> / BcMachine<3> as started by the host
   Mailbox *mbox;
@@ -71,6 +80,9 @@ struct ResidentCtx {
   unsigned tag_base;  // tags of this launch are tag_base + epoch + 1: the rows need no zeroing between launches
   long long spin_ticks;  // budget of one wait (s_memrealtime ticks)
   int sabotage_epoch;    // test hook (BRDF_HIP_RESIDENT_SABOTAGE): the last workgroup withholds its row at this epoch; -1 = never
+  int replicas;          // copies of the group rows in use (1..kReplicas): readers pick copy blockIdx % replicas
+  long long *trace;      // diagnostic builds (-DBRDF_STAMPS): [workgroup][8] s_memrealtime stamps of epoch trace_epoch
+  int trace_epoch;
 };
 
 // METHOD 0 dlevmar_dif, 1 dlevmar_bc_dif / bc_der, 2 dlevmar_der (analytic Jacobian, lm_core.c:64-432)
@@ -84,6 +96,11 @@ __device__ __forceinline__ void put_value(u64 *rows, int stride, int word, int c
 }
 __device__ __forceinline__ u64 get_granule(const u64 *g) { return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double join_halves(u64 lo, u64 hi) { return __longlong_as_double((long long)((lo & 0xffffffffull) | (hi << 32))); }
+__device__ __forceinline__ double read_lane(double v, int lane) {  // lane is wave-uniform
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
 
 // The sweeps of this kernel are bound by fp64 issue, not by memory, so the accumulations are written as fused
 // multiply-adds (one instruction and one rounding instead of two; the library is otherwise built with
@@ -109,19 +126,55 @@ __device__ __forceinline__ double div_by(double x, double d, double r) {
 
 #ifdef BRDF_STAMPS
 #define RSTAMP(i) do { const long long now_ = clock64(); st_[i] += now_ - last_; last_ = now_; } while (0)
+// one epoch's timeline of EVERY workgroup (arrival skew, hop latencies): slot <- s_memrealtime (100 MHz) or a counter
+#define RTRACE(ctx_, epoch_, slot_, val_) do { if ((ctx_).trace && (int)(epoch_) == (ctx_).trace_epoch && (threadIdx.x & 63) == 0) (ctx_).trace[blockIdx.x * 8 + (slot_)] = (long long)(val_); } while (0)
 #else
 #define RSTAMP(i) do {} while (0)
+#define RTRACE(ctx_, epoch_, slot_, val_) do {} while (0)
 #endif
 
-// Reduction of NS sums and one max over the seven sample waves (executed by those waves only; the control wave
-// joins the two barriers): two DPP steps inside each row of 16 lanes leave the sum of every 4 consecutive lanes in
-// lanes 3,7,11,..; those park their values as buf[slot][worker/4]; sample wave w (1..7) then owns slots {w-1, w+6}:
-// each lane adds its entries and one DPP tree per slot finishes it.  A pure function of NS: reproducible.
+// ---- where a lane's samples live ---------------------------------------------------------------------------------
+// Fields: 0 c0, 1 x, 2 q1, 3 q2 (Ward only), and for dlevmar_dif 4 hx = f(p), 5 wrk = f(p+Dp), 6 tb = Broyden scalar.
+// RegSamples: registers (every index a compile-time constant: the loops over k are fully unrolled).
+// LdsSamples: the control wave's copy, [field][k][lane] in LDS, swept by a rolled loop.
+constexpr int kFc0 = 0, kFx = 1, kFq1 = 2, kFq2 = 3, kFhx = 4, kFwrk = 5, kFtb = 6;
+template <int METHOD>
+constexpr int sample_fields() { return METHOD == 0 ? 7 : 4; }
+
+template <int METHOD>
+struct RegSamples {
+  static constexpr bool kUnrolled = true;
+  double v[sample_fields<METHOD>()][kRSpt];
+  __device__ __forceinline__ double get(int f, int k) const { return v[f][k]; }
+  __device__ __forceinline__ void set(int f, int k, double x) { v[f][k] = x; }
+};
+template <int METHOD>
+struct LdsSamples {
+  static constexpr bool kUnrolled = false;
+  double *base;  // + lane
+  __device__ __forceinline__ double get(int f, int k) const { return base[(f * kRSpt + k) * kWave]; }
+  __device__ __forceinline__ void set(int f, int k, double x) { base[(f * kRSpt + k) * kWave] = x; }
+};
+
+template <bool UNROLLED, class F>
+__device__ __forceinline__ void for_samples(int nk, F &&f) {
+  if constexpr (UNROLLED) {
+#pragma unroll
+    for (int k = 0; k < kRSpt; ++k)
+      if (k < nk) f(k);
+  } else {  // two samples per trip: one sample's dependent chain (exp, Broyden, 13 accumulations) alone leaves the pipe idle
+#pragma unroll 2
+    for (int k = 0; k < nk; ++k) f(k);
+  }
+}
+
+// Reduction of NS sums and one max over the eight waves: two DPP steps inside each row of 16 lanes leave the sum of
+// every 4 consecutive lanes in lanes 3,7,11,..; those park their values as buf[slot][thread/4]; wave w then owns slots
+// {w, w+8}: each lane adds its two entries and one DPP tree per slot finishes it.  A pure function of NS: reproducible.
 template <int NS>
 __device__ __forceinline__ void worker_reduce(const double *acc, double mx, double *buf, double *out) {
   const int lane = threadIdx.x & (kWave - 1);
-  const int wave = (threadIdx.x >> 6) - 1;       // 0..6
-  const int wt = threadIdx.x - kWave;            // 0..447
+  const int wave = threadIdx.x >> 6;  // 0..7
   double v[NS + 1];
 #pragma unroll
   for (int k = 0; k < NS; ++k) {
@@ -136,21 +189,20 @@ __device__ __forceinline__ void worker_reduce(const double *acc, double mx, doub
     t = fmax(t, dpp_move<0x112, 0xf, 0xf>(t, 0.0));
     v[NS] = t;
   }
-  if ((wt & 3) == 3) {
+  if ((threadIdx.x & 3) == 3) {
 #pragma unroll
-    for (int k = 0; k <= NS; ++k) buf[k * kRedCols + (wt >> 2)] = v[k];
+    for (int k = 0; k <= NS; ++k) buf[k * kRedCols + (threadIdx.x >> 2)] = v[k];
   }
   __syncthreads();  // X1
-  for (int k = wave; k <= NS; k += kRWorkers / kWave) {  // wave-uniform loop
+  for (int k = wave; k <= NS; k += kRThreads / kWave) {  // wave-uniform loop
     const double *src = buf + k * kRedCols;
-    const bool two = lane + kWave < kRedCols;
     double s = src[lane];
     if (k < NS) {
-      s += two ? src[lane + kWave] : 0.0;
+      s += src[lane + kWave];
       s = wave_reduce_to_last<OpSum>(s);
       if (lane == kWave - 1) out[k] = s;
     } else {
-      s = fmax(s, two ? src[lane + kWave] : 0.0);
+      s = fmax(s, src[lane + kWave]);
       s = wave_reduce_to_last<OpMax>(s);
       if (lane == kWave - 1) out[kSums] = s;
     }
@@ -162,120 +214,290 @@ __device__ __forceinline__ void worker_reduce(const double *acc, double mx, doub
 // 256 rows -- was measured at 6.2 us: 256 readers per line make the few hundred lines of the row table a hot spot
 // of the memory side; more loads in flight per reader made it slower, not faster.)
 //
-//   level 1  rows [parity][word][workgroup], word = 2*slot + half: every workgroup publishes its NS sums + max
-//            (lanes 0..NS-1 and lane 13, two granules each).  Workgroups are grouped 16 by 16; the first one of a group
-//            is its leader: lanes 0..15 of its control wave each gather one member's row (a wave load instruction
-//            reads 16 consecutive words = ONE line), fold the 16 rows with a DPP row reduction (fixed order) and
-//            lane 15 publishes the group's sums into
-//   level 2  groups [parity][word][group]: 16 groups x 8 B = one line per word.  Every workgroup (leaders too)
-//            gathers the <=16 group rows the same way and folds them: identical bits everywhere.
+//   level 1  rows [parity][group][word][member], word = 2*slot + half: workgroups are grouped 16 by 16 and a group's
+//            28 words x 16 members are 3.5 KB of CONSECUTIVE granules.  Every workgroup publishes its NS sums + max
+//            (lanes 0..NS-1 and lane 13, two granules each).  One workgroup of a group is its leader (a different
+//            position in every group, so that the leaders -- blockIdx % 8 tells which workgroups share an XCD -- are spread
+//            over the XCDs).  ALL 64 lanes of its control wave gather: lane l takes member l % 16 of slot 4j + l / 16,
+//            j = 0..3 (a wave load instruction reads 4 whole lines; 8 instructions fetch a TRIAL row set), so the 16
+//            members of a slot sit in one DPP row and four row reductions (fixed order) fold everything.  (The first
+//            version kept ONE table [word][256 workgroups]: a leader's 16 active lanes issued 28 loads, 2 KB apart, per
+//            attempt, and an attempt took ~1.5 us -- the in-kernel trace showed level 1 alone at 3.4 us.)
+//   level 2  groups [parity][replica][word][group]: the leader broadcasts each folded value inside its DPP row
+//            (row_newbcast) and lanes 0..replicas-1 of the row store one copy each, so that a line is polled by #CUs /
+//            replicas workgroups instead of all of them (one copy: +0.9 us).  Every workgroup (leaders too) gathers the
+//            <= 16 group rows of copy blockIdx % replicas the same way and folds them: identical bits everywhere.
 //
-// On level 2 (256 readers per line) a lane first probes ONE word of its row (the last one its producer stores) and
-// only then loads the row, and waits between probes: the lines being polled are the ones the producers have to
-// write.  On level 1 (one reader per line) the row is simply re-read until all its tags match.  false = wait abandoned.
+// A gather re-reads its block until every tag matches; false = wait abandoned (spin budget, or somebody else gave up).
 constexpr int kGroup = 16;
-constexpr int kGroupStride = 16;  // group rows per granule word (>= ceil(#CUs / kGroup)), one 128-B line
+constexpr int kMaxGroups = 16;  // >= ceil(#CUs / kGroup); also the width of a level-2 row: one 128-B line
+constexpr int kReplicas = 8;
+constexpr size_t kBlockGranules = (size_t)kRowWords * kGroup;                    // one group's rows / one copy of the group rows
+constexpr size_t kRowsGranules = 2 * (size_t)kMaxGroups * kBlockGranules;         // [parity][group]
+constexpr size_t kGroupsGranules = 2 * (size_t)kReplicas * kBlockGranules;        // [parity][replica]
 
 template <int NS>
-__device__ __forceinline__ bool gather_row(const ResidentCtx &ctx, const u64 *g, int stride, unsigned tag, bool probe, bool active,
-                                           double (&pv)[NS], double &pmx) {
+__device__ __forceinline__ constexpr bool slot_used(int v) { return v < NS || v == kSums; }
+
+// val[j] <- slot 4j + lane/16 of column lane%16 of the block (0 where the slot is not used or the column >= ncols)
+template <int NS>
+__device__ __forceinline__ bool gather_block(const ResidentCtx &ctx, const u64 *blk, unsigned tag, int ncols, double (&val)[4],
+                                             unsigned *polls) {
+  const int lane = threadIdx.x;  // control wave = wave 0
+  const int col = lane & 15, r = lane >> 4;
+  const long long t0 = (long long)wall_clock64();
+  for (unsigned spins = 0;; ++spins) {
+    u64 lo[4], hi[4];
+    bool ready = true;
 #pragma unroll
-  for (int k = 0; k < NS; ++k) pv[k] = 0.0;
-  pmx = 0.0;
-  bool failed = false;
-  if (active) {
-    const long long t0 = (long long)wall_clock64();
-    for (unsigned spins = 0;; ++spins) {
-      if (!probe || (unsigned)(get_granule(g + (size_t)(2 * kSums + 1) * stride) >> 32) == tag) {
-        u64 w[2 * NS + 2];
-#pragma unroll
-        for (int k = 0; k < 2 * NS; ++k) w[k] = get_granule(g + (size_t)k * stride);
-        w[2 * NS] = get_granule(g + (size_t)(2 * kSums) * stride);
-        w[2 * NS + 1] = get_granule(g + (size_t)(2 * kSums + 1) * stride);
-        bool ready = true;
-#pragma unroll
-        for (int k = 0; k < 2 * NS + 2; ++k) ready = ready && ((unsigned)(w[k] >> 32) == tag);
-        if (ready) {
-#pragma unroll
-          for (int k = 0; k < NS; ++k) pv[k] = join_halves(w[2 * k], w[2 * k + 1]);
-          pmx = join_halves(w[2 * NS], w[2 * NS + 1]);
-          break;
+    for (int j = 0; j < 4; ++j) {
+      lo[j] = hi[j] = (u64)tag << 32;
+      if ((4 * j < NS) || (4 * j <= kSums && kSums < 4 * j + 4)) {  // (compile time) some row of this instruction is used
+        const int v = 4 * j + r;
+        if (slot_used<NS>(v) && col < ncols) {
+          lo[j] = get_granule(blk + (size_t)(2 * v) * kGroup + col);
+          hi[j] = get_granule(blk + (size_t)(2 * v + 1) * kGroup + col);
         }
       }
-      if ((spins & 63u) == 63u) {
-        if (__hip_atomic_load(&ctx.ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
-            (long long)wall_clock64() - t0 > ctx.spin_ticks) {
-          __hip_atomic_store(&ctx.ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          failed = true;
-          break;
-        }
-      }
-      if (probe)
-        __builtin_amdgcn_s_sleep(2);  // many readers of one line: leave the line to its producers between probes
-      else
-        __builtin_amdgcn_s_sleep(1);
     }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ready = ready && (unsigned)(lo[j] >> 32) == tag && (unsigned)(hi[j] >> 32) == tag;
+    if (__all(ready)) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) val[j] = join_halves(lo[j], hi[j]);
+      *polls = spins;
+      return true;
+    }
+    if ((spins & 63u) == 63u) {  // (wave-uniform)
+      if (__hip_atomic_load(&ctx.ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
+          (long long)wall_clock64() - t0 > ctx.spin_ticks) {
+        __hip_atomic_store(&ctx.ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+      }
+    }
+    __builtin_amdgcn_s_sleep(1);
   }
-  return !__any(failed);
+}
+
+// folds the 16 columns of every slot: the total of slot 4j + r ends in lane 16r + 15 of val[j] (the max slot by max)
+__device__ __forceinline__ void fold_block(double (&val)[4]) {
+  const int r = (int)threadIdx.x >> 4;
+  const double mx = row_reduce_to_last<OpMax>(val[kSums / 4]);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) val[j] = row_reduce_to_last<OpSum>(val[j]);
+  if (r == (kSums & 3)) val[kSums / 4] = mx;
 }
 
 template <int NS>
 __device__ __forceinline__ bool control_exchange(const ResidentCtx &ctx, unsigned epoch, double *sums, int *s_abort,
                                                  long long *st_, long long &last_) {
   const int lane = threadIdx.x;  // control wave = wave 0
+  const int col = lane & 15, r = lane >> 4;
   const int G = gridDim.x;
   const int grp = blockIdx.x / kGroup, ngrp = (G + kGroup - 1) / kGroup;
+  const int members = min(kGroup, G - grp * kGroup);
+  const int leader = grp * kGroup + (grp & 7) % members;
   const unsigned tag = ctx.tag_base + epoch + 1u;
-  u64 *rows = ctx.rows + (size_t)(epoch & 1u) * kRowWords * kRowStride;
-  u64 *groups = ctx.groups + (size_t)(epoch & 1u) * kRowWords * kGroupStride;
+  u64 *rows = ctx.rows + ((size_t)(epoch & 1u) * kMaxGroups + grp) * kBlockGranules;
+  u64 *groups = ctx.groups + (size_t)(epoch & 1u) * kReplicas * kBlockGranules;
   const bool withhold = (int)epoch == ctx.sabotage_epoch && blockIdx.x == gridDim.x - 1;  // test hook, see ResidentCtx
-  if (lane < NS && !withhold)
-    put_value(rows, kRowStride, 2 * lane, blockIdx.x, tag, sums[lane]);
-  else if (lane == kSums && !withhold)
-    put_value(rows, kRowStride, 2 * kSums, blockIdx.x, tag, sums[kSums]);
+  if (slot_used<NS>(lane) && lane <= kSums && !withhold) put_value(rows, kGroup, 2 * lane, blockIdx.x % kGroup, tag, sums[lane]);
 
-  double pv[NS], pmx;
-  if (blockIdx.x % kGroup == 0) {  // group leader (workgroup-uniform branch)
-    const int m = grp * kGroup + lane;
-    if (!gather_row<NS>(ctx, rows + m, kRowStride, tag, /*probe=*/false, lane < kGroup && m < G, pv, pmx)) {
+  double val[4];
+  unsigned polls = 0;
+  if ((int)blockIdx.x == leader) {  // group leader (workgroup-uniform branch)
+    if (!gather_block<NS>(ctx, rows, tag, members, val, &polls)) {
       *s_abort = 1;
       return false;
     }
+    RTRACE(ctx, epoch, 6, polls + 1);
+    fold_block(val);
 #pragma unroll
-    for (int k = 0; k < NS; ++k) {
-      const double t = row_reduce_to_last<OpSum>(pv[k]);
-      if (lane == kGroup - 1) put_value(groups, kGroupStride, 2 * k, grp, tag, t);
+    for (int j = 0; j < 4; ++j) {
+      const double t = dpp_move<0x15F, 0xf, 0xf>(val[j], 0.0);  // row_newbcast:15: the row's total in all 16 lanes of the row
+      const int v = 4 * j + r;
+      if (slot_used<NS>(v) && col < ctx.replicas) put_value(groups + (size_t)col * kBlockGranules, kGroup, 2 * v, grp, tag, t);
     }
-    const double t = row_reduce_to_last<OpMax>(pmx);
-    if (lane == kGroup - 1) put_value(groups, kGroupStride, 2 * kSums, grp, tag, t);
   }
   RSTAMP(2);
-  if (!gather_row<NS>(ctx, groups + lane, kGroupStride, tag, /*probe=*/true, lane < ngrp, pv, pmx)) {
+  RTRACE(ctx, epoch, 3, wall_clock64());
+  if (!gather_block<NS>(ctx, groups + (size_t)(blockIdx.x % ctx.replicas) * kBlockGranules, tag, ngrp, val, &polls)) {
     *s_abort = 1;
     return false;
   }
+  fold_block(val);
 #pragma unroll
-  for (int k = 0; k < NS; ++k) {
-    const double t = row_reduce_to_last<OpSum>(pv[k]);
-    if (lane == kGroup - 1) sums[k] = t;
-  }
-  {
-    const double t = row_reduce_to_last<OpMax>(pmx);
-    if (lane == kGroup - 1) sums[kSums] = t;
+  for (int j = 0; j < 4; ++j) {
+    const int v = 4 * j + r;
+    if (slot_used<NS>(v) && col == kGroup - 1) sums[v] = val[j];
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   RSTAMP(3);
+  RTRACE(ctx, epoch, 4, wall_clock64());
+  RTRACE(ctx, epoch, 7, polls);
   return true;
 }
 
+// ---- one pass over a lane's samples ------------------------------------------------------------------------------
+// Executed by all eight waves: waves 1..7 on RegSamples (unrolled), the control wave on LdsSamples (rolled).  Leaves the
+// lane's partial sums in acc[] / mx and returns the number of sum slots of the request kind (a wave-uniform value).
+// `pend` (dlevmar_dif): the machine adopted the Broyden update of the previous trial; tb[] holds its scalar and
+// dpp[] its Dp: J += tb Dp^T is applied to the row while it is being read (lm_core.c:760-766).
+template <int MODEL, int METHOD, bool FAST, class Store>
+__device__ __forceinline__ void sweep_pass(int kind, const PassUniforms<MODEL> &u, Store &st, double *jl, int tid, int nk, unsigned okm,
+                                           bool pend, const double *dpp, double *acc, double &mx) {
+  constexpr bool U = Store::kUnrolled;
+  constexpr bool W2 = BrdfModel<MODEL>::prep_planes == 2;
+  auto prep = [&](int k) { return Prep{st.get(kFq1, k), W2 ? st.get(kFq2, k) : 0.0}; };
+  // only the LAST occupied slot can hold lanes without a sample (slot k is full when (k+1)*512 <= tile): the masking
+  // code sits behind a wave-uniform branch and is skipped for the other slots
+  auto dead = [&](int k) { return k == nk - 1 && !(okm >> k & 1u); };
+  switch (kind) {
+  case RQ_EVAL:  // (the four kinds only dlevmar_bc_dif / bc_der / der issue are compiled into those kernels only)
+    if constexpr (METHOD != 0) {
+      for_samples<U>(nk, [&](int k) {
+        const double f = model_value<MODEL, FAST>(u, st.get(kFc0, k), prep(k));
+        double e = st.get(kFx, k) - f;
+        if (k == nk - 1 && dead(k)) e = 0.0;
+        acc[0] = fma(e, e, acc[0]);
+        mx = fmax(mx, fabs(e));
+      });
+    }
+    break;
+  case RQ_SCALED:
+    if constexpr (METHOD != 0) {
+      for_samples<U>(nk, [&](int k) {
+        const double f = model_value<MODEL, FAST>(u, st.get(kFc0, k), prep(k));
+        double t = (st.get(kFx, k) - f) / u.scal;
+        if (k == nk - 1 && dead(k)) t = 0.0;
+        acc[0] = fma(t, t, acc[0]);
+      });
+    }
+    break;
+  case RQ_EVAL_MULTI:
+    if constexpr (METHOD != 0) {
+      for_samples<U>(nk, [&](int k) {
+        const double c0 = st.get(kFc0, k), x = st.get(kFx, k);
+        const Prep q = prep(k);
+#pragma unroll
+        for (int j = 0; j < kMaxCand; ++j)
+          if (j < u.ncand) {
+            double e = x - model_value_k<MODEL, FAST>(u, j, c0, q);
+            if (k == nk - 1 && dead(k)) e = 0.0;
+            acc[j] = fma(e, e, acc[j]);
+          }
+      });
+    }
+    break;
+  case RQ_JAC:
+    if constexpr (METHOD != 0) {
+      for_samples<U>(nk, [&](int k) {
+        double f0 = 0.0, j[kM];
+        if (u.analytic)  // dlevmar_bc_der / dlevmar_der with the model's analytic Jacobian
+          model_an_row<MODEL, FAST>(u, st.get(kFc0, k), prep(k), f0, j);
+        else
+          model_fd_row<MODEL, FAST>(u, st.get(kFc0, k), prep(k), true, f0, 0.0, false, j);
+        double e = st.get(kFx, k) - f0;
+        if (k == nk - 1 && dead(k)) e = j[0] = j[1] = j[2] = 0.0;
+        acc_normal_eq_fma(j, e, acc, acc + kNL);
+        acc[kNL + kM] = fma(e, e, acc[kNL + kM]);
+      });
+    }
+    break;
+  case RQ_DIF_INIT:
+    if constexpr (METHOD == 0) {
+      for_samples<U>(nk, [&](int k) {
+        const double h = model_value<MODEL, FAST>(u, st.get(kFc0, k), prep(k));
+        st.set(kFhx, k, h);
+        double e = st.get(kFx, k) - h;
+        if (k == nk - 1 && dead(k)) e = 0.0;
+        acc[0] = fma(e, e, acc[0]);
+      });
+    }
+    break;
+  case RQ_DIF_JAC:
+    if constexpr (METHOD == 0) {
+      for_samples<U>(nk, [&](int k) {
+        const int s = k * kRThreads + tid;
+        const double h = st.get(kFhx, k);
+        double f0 = 0.0, j[kM];
+        model_fd_row<MODEL, FAST>(u, st.get(kFc0, k), prep(k), false, f0, h, true, j);
+        double e = st.get(kFx, k) - h;
+        if (k == nk - 1 && dead(k)) e = j[0] = j[1] = j[2] = 0.0;
+        jl[s] = j[0];
+        jl[kRCap + s] = j[1];
+        jl[2 * kRCap + s] = j[2];
+        acc_normal_eq_fma(j, e, acc, acc + kNL);
+      });
+    }
+    break;
+  case RQ_DIF_TRIAL:  // speculative protocol: the Broyden-updated row is formed for the sums only (see the file comment)
+    if constexpr (METHOD == 0) {
+      const double rinv = 1.0 / u.dp_l2;
+      for_samples<U>(nk, [&](int k) {
+        const int s = k * kRThreads + tid;
+        const double h = st.get(kFhx, k), x = st.get(kFx, k);
+        const double w = model_value_q<MODEL, FAST>(u, st.get(kFc0, k), prep(k));
+        double jo[kM] = {jl[s], jl[kRCap + s], jl[2 * kRCap + s]};
+        if (pend) {  // adopt the previous trial's update: the same operation that formed its jn[] below
+          const double tp = st.get(kFtb, k);
+#pragma unroll
+          for (int j = 0; j < kM; ++j) jo[j] = fma(tp, dpp[j], jo[j]);
+          jl[s] = jo[0];
+          jl[kRCap + s] = jo[1];
+          jl[2 * kRCap + s] = jo[2];
+        }
+        // broyden_row() (lm_core.c:760-766) with fused multiply-adds (the sweeps are bound by fp64 issue) and the division
+        // by ||Dp||^2 done by div_by()
+        double t = jo[0] * u.dp[0], jn[kM];
+        t = fma(jo[1], u.dp[1], t);
+        t = fma(jo[2], u.dp[2], t);
+        t = div_by(w - h - t, u.dp_l2, rinv);
+#pragma unroll
+        for (int j = 0; j < kM; ++j) jn[j] = fma(t, u.dp[j], jo[j]);
+        double en = x - w, eo = x - h;
+        if (k == nk - 1 && dead(k)) en = eo = jn[0] = jn[1] = jn[2] = 0.0;
+        st.set(kFwrk, k, w);
+        st.set(kFtb, k, t);
+        acc[0] = fma(en, en, acc[0]);
+        acc_normal_eq_fma(jn, en, acc + 1, acc + 1 + kNL);
+        acc[1 + kNL + kM + 0] = fma(jn[0], eo, acc[1 + kNL + kM + 0]);
+        acc[1 + kNL + kM + 1] = fma(jn[1], eo, acc[1 + kNL + kM + 1]);
+        acc[1 + kNL + kM + 2] = fma(jn[2], eo, acc[1 + kNL + kM + 2]);
+      });
+    }
+    break;
+  default: break;  // unknown request: the control wave will not survive it either
+  }
+}
+
+// the matching reduction (the number of sums depends on the request kind only: wave-uniform)
+template <int METHOD>
+__device__ __forceinline__ void reduce_pass(int kind, const double *acc, double mx, double *red, double *sums) {
+  if constexpr (METHOD == 0) {
+    switch (kind) {
+    case RQ_DIF_JAC: worker_reduce<SumLayout<kM>::DIF_JAC>(acc, mx, red, sums); break;
+    case RQ_DIF_TRIAL: worker_reduce<SumLayout<kM>::DIF_TRIAL>(acc, mx, red, sums); break;
+    default: worker_reduce<1>(acc, mx, red, sums); break;
+    }
+  } else {
+    switch (kind) {
+    case RQ_JAC: worker_reduce<SumLayout<kM>::JAC>(acc, mx, red, sums); break;
+    case RQ_EVAL_MULTI: worker_reduce<kMaxCand>(acc, mx, red, sums); break;
+    default: worker_reduce<1>(acc, mx, red, sums); break;
+    }
+  }
+}
+
 // BATCHED = false: one fit spread over the grid (ctx).  BATCHED = true: one workgroup per fit of 1024 < n <= 4096 samples
-// (bctx, batch_fit.h) -- the same control wave / sample waves / LDS Jacobian, no exchange between workgroups, the
-// speculative dlevmar_dif protocol (one pass per LM iteration), the machine started on the device.
+// (bctx, batch_fit.h) -- the same eight waves / LDS Jacobian, no exchange between workgroups, the speculative
+// dlevmar_dif protocol (one pass per LM iteration), the machine started on the device.
 template <int MODEL, int METHOD, bool FAST, bool BATCHED>
 __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx, BatchCtx bctx) {
   using Machine = RMachine<METHOD>;
   using Mdl = BrdfModel<MODEL>;
+  constexpr int NF = sample_fields<METHOD>();
   static_assert(sizeof(Machine) % 4 == 0, "machine copied as dwords");
   __shared__ Machine sm;
   __shared__ PassUniforms<MODEL> su;
@@ -283,6 +505,7 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
   __shared__ double sums[kSlots];
   __shared__ double dp_prev[kM + 1];  // Dp and ||Dp||^2 of the last trial (dif)
   __shared__ int s_abort, s_bad;
+  __shared__ double cst[NF * kRSpt * kWave];  // the control wave's samples
   constexpr int kJl = (METHOD == 0) ? 3 * kRCap : 2;
   __shared__ double jl[kJl];  // dif: the secant Jacobian, SoA planes
 
@@ -318,10 +541,71 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
     else
       su.build(sm.h.req, true, METHOD == 2);
   }
-  __syncthreads();
+
+  // ---- the resident tile: one HBM read ---------------------------------------------------------------------------
+  int vb = BATCHED ? 0 : (int)blockIdx.x;  // same XCD-contiguous dealing of tiles as the launch chain
+  if (!BATCHED && (G & 7) == 0) vb = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+  const int tile = (n + G - 1) / G;  // <= kRTile, checked on the host
+  const int begin = vb * tile;
+  const int end = min(n, begin + tile);
+  const double *pc0 = BATCHED ? bctx.angles + (size_t)fit * 3 * n : ctx.c0;
+  const double *pc1 = BATCHED ? pc0 + n : ctx.c1;
+  const double *pc2 = BATCHED ? pc0 + 2 * (size_t)n : ctx.c2;
+  const double *px = BATCHED ? bctx.x + (size_t)fit * n : ctx.x;
+  const int nk = (tile + kRThreads - 1) / kRThreads;  // occupied sample slots of a lane (workgroup-uniform)
+  RegSamples<METHOD> rs;
+  LdsSamples<METHOD> ls{cst + (tid & (kWave - 1))};
+  unsigned okm = 0;
+  {
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < kRSpt; ++k) {
+      const int i = begin + tid + k * kRThreads;
+      const bool ok = i < end;
+      okm |= ok ? (1u << k) : 0u;
+      const int ii = ok ? i : begin;
+      const double r0 = pc0[ii];
+      const double r1 = Mdl::uses_c1 ? pc1[ii] : 0.0;
+      const double r2 = Mdl::uses_c2 ? pc2[ii] : 0.0;
+      const Prep q = Mdl::template prepare<FAST>(r0, r1, r2);
+      rs.v[kFc0][k] = r0;
+      rs.v[kFx][k] = px[ii];
+      rs.v[kFq1][k] = q.q1;
+      rs.v[kFq2][k] = q.q2;
+      if constexpr (METHOD == 0) rs.v[kFhx][k] = rs.v[kFwrk][k] = rs.v[kFtb][k] = 0.0;
+      if (FAST && ok && !Mdl::domain_ok(r0, r1, r2)) bad = true;
+    }
+    if constexpr (BATCHED) {
+      if (FAST && bad) s_bad = 1;  // benign race: every writer stores 1
+    } else {
+      if (FAST && bad) __hip_atomic_store(&ctx.ctl->domain_bad, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (wave == 0) {  // park the control wave's samples in LDS
+#pragma unroll
+      for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int k = 0; k < kRSpt; ++k) ls.set(f, k, rs.v[f][k]);
+    }
+  }
+  __syncthreads();  // machine, uniforms, s_bad and the parked samples are visible
+
+  int cur_sel_hx = 0, cur_sel_j = 0;
+  // what every wave does at the top of a pass (dlevmar_dif): learn what the machine decided about the previous trial
+  auto decisions = [&](auto &st, bool &pend) {
+    pend = false;
+    if constexpr (METHOD == 0) {
+      pend = sm.h.req.sel_j != cur_sel_j;  // the Broyden update was adopted: J += tb Dp^T, applied by the next trial sweep
+      if (pend && sm.h.req.kind != RQ_DIF_TRIAL) pend = false;  // (a fresh FD Jacobian overwrites J anyway)
+      cur_sel_j = sm.h.req.sel_j;
+      if (sm.h.req.sel_hx != cur_sel_hx) {  // step accepted: hx <- f(p + Dp)
+        for_samples<std::remove_reference<decltype(st)>::type::kUnrolled>(nk, [&](int k) { st.set(kFhx, k, st.get(kFwrk, k)); });
+        cur_sel_hx = sm.h.req.sel_hx;
+      }
+    }
+  };
 
   if (wave == 0) {
-    // =========================== control wave: exchange, fold, LM step ===========================================
+    // =========================== control wave: sweep from LDS, exchange, fold, LM step ============================
     // All 64 lanes execute the scalar step with identical values (stream_fit.hip explains why that beats one lane).
     long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long last_ = clock64();
@@ -332,11 +616,24 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
       const int kind = sm.h.req.kind;
       if (kind == RQ_DONE) break;
       if (kind == RQ_JAC || kind == RQ_DIF_JAC) ++n_jac;
-      __syncthreads();  // X1 (worker_reduce)
-      __syncthreads();  // X2: sums[] hold this workgroup's partial sums
-      RSTAMP(1);
+      RTRACE(ctx, epoch, 0, wall_clock64());
+      {
+        bool pend;
+        decisions(ls, pend);
+        double acc[kSums];
+#pragma unroll
+        for (int k = 0; k < kSums; ++k) acc[k] = 0.0;
+        double mx = 0.0;
+        const double dpp[kM] = {dp_prev[0], dp_prev[1], dp_prev[2]};
+        sweep_pass<MODEL, METHOD, FAST>(kind, su, ls, jl, tid, nk, okm, pend, dpp, acc, mx);
+        RSTAMP(5);  // the control wave's own sweep
+        RTRACE(ctx, epoch, 1, wall_clock64());
+        reduce_pass<METHOD>(kind, acc, mx, red, sums);  // X1, X2: sums[] hold this workgroup's partial sums
+      }
+      RSTAMP(1);  // reduction + waiting for the slowest wave
+      RTRACE(ctx, epoch, 2, wall_clock64());
       bool alive = true;
-      if constexpr (BATCHED && FAST) {  // the sample waves looked at the cosines while loading the tile (before X1)
+      if constexpr (BATCHED && FAST) {  // every wave looked at its cosines while loading the tile
         if (epoch == 0) {
           if (s_bad) {  // log of a non-positive cosine: leave this fit to the exact kernel
             if (tid == 0) bctx.flags[fit] = kNeedsExact;
@@ -363,7 +660,7 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
         }
       }
       if (!alive) {  // give up: the host sees no `done`, reads ctl->abort and falls back
-        __syncthreads();  // B (the sample waves read s_abort behind it)
+        __syncthreads();  // B (the other waves read s_abort behind it)
         return;
       }
       if (kind == RQ_DIF_TRIAL) {
@@ -371,13 +668,39 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
         for (int j = 0; j < kM; ++j) dp_prev[j] = su.dp[j];
         dp_prev[kM] = su.dp_l2;
       }
-      sm.template step<true>(sums, sums[kSums]);
-      if (sm.h.req.kind != RQ_DONE) {
+      {  // the LM step on a register copy of the machine's hot half (see the file comment)
+        // The machine is stepped where it lives, in LDS.  Stepping a REGISTER copy of its busy half (Machine::Core; the
+        // machines are laid out for it) was measured and lost: 9600 against 8100 cycles per dlevmar_dif step with 22 VGPRs
+        // spilled, 10600 with 105; dlevmar_bc_dif's machine (line search, 8 projected-gradient candidates) spilled 160 and
+        // ran 30 % slower.  -DBRDF_STEP_IN_REGS builds that variant.
+#ifdef BRDF_STEP_IN_REGS
+        constexpr bool kStepInRegs = METHOD != 1;
+#else
+        constexpr bool kStepInRegs = false;
+#endif
+        if constexpr (!kStepInRegs) {
+          sm.template step<true>(sums, sums[kSums]);
+        } else {
+        typename Machine::Core h = sm.h;  // (the request stays in LDS: the step only writes it)
+#ifndef BRDF_CORE_PLAIN
+        Machine::uniform_ints(h);
+#endif
         if constexpr (METHOD == 1)
-          su.build(sm.h.req, /*need_base=*/false, sm.c.analytic_jac != 0);
+          Machine::template run<true, true, false>(sm.c, h, sm.h.cool, sm.h.req, sums, sums[kSums], true);
+        else if constexpr (METHOD == 0)
+          Machine::template run<true>(sm.c, h, sm.h.cool, sm.h.req, sums, sums[kSums]);
         else
-          su.build(sm.h.req, /*need_base=*/false, METHOD == 2);
+          Machine::template run<true>(sm.c, h, sm.h.req, sums, sums[kSums]);
+        static_cast<typename Machine::Core &>(sm.h) = h;
+        }
+        if (sm.h.req.kind != RQ_DONE) {
+          if constexpr (METHOD == 1)
+            su.build(sm.h.req, /*need_base=*/false, sm.c.analytic_jac != 0);
+          else
+            su.build(sm.h.req, /*need_base=*/false, METHOD == 2);
+        }
       }
+      RTRACE(ctx, epoch, 5, wall_clock64());
       __syncthreads();  // B: the next request and its uniforms are in LDS
       RSTAMP(4);
     }
@@ -414,195 +737,19 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
     return;
   }
 
-  // ============================= sample waves: the resident tile and the sweeps ================================
-  const int wt = tid - kWave;  // 0..447
-  int vb = BATCHED ? 0 : (int)blockIdx.x;  // same XCD-contiguous dealing of tiles as the launch chain
-  if (!BATCHED && (G & 7) == 0) vb = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
-  const int tile = (n + G - 1) / G;  // <= kRTile, checked on the host
-  const int begin = vb * tile;
-  const int end = min(n, begin + tile);
-  const double *pc0 = BATCHED ? bctx.angles + (size_t)fit * 3 * n : ctx.c0;
-  const double *pc1 = BATCHED ? pc0 + n : ctx.c1;
-  const double *pc2 = BATCHED ? pc0 + 2 * (size_t)n : ctx.c2;
-  const double *px = BATCHED ? bctx.x + (size_t)fit * n : ctx.x;
-  const int nk = (tile + kRWorkers - 1) / kRWorkers;  // occupied sample slots of a lane (workgroup-uniform)
-  double s0[kRSpt], sx[kRSpt];
-  Prep pq[kRSpt];
-  unsigned okm = 0;
-  {
-    bool bad = false;
-#pragma unroll
-    for (int k = 0; k < kRSpt; ++k) {
-      const int i = begin + wt + k * kRWorkers;
-      const bool ok = i < end;
-      okm |= ok ? (1u << k) : 0u;
-      const int ii = ok ? i : begin;
-      s0[k] = pc0[ii];
-      const double r1 = Mdl::uses_c1 ? pc1[ii] : 0.0;
-      const double r2 = Mdl::uses_c2 ? pc2[ii] : 0.0;
-      sx[k] = px[ii];
-      pq[k] = Mdl::template prepare<FAST>(s0[k], r1, r2);
-      if (FAST && ok && !Mdl::domain_ok(s0[k], r1, r2)) bad = true;
-    }
-    if constexpr (BATCHED) {
-      if (FAST && bad) s_bad = 1;  // benign race: every writer stores 1
-    } else {
-      if (FAST && bad) __hip_atomic_store(&ctx.ctl->domain_bad, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-  double hx[METHOD == 0 ? kRSpt : 1], wrk[METHOD == 0 ? kRSpt : 1];
-  if constexpr (METHOD == 0) {
-#pragma unroll
-    for (int k = 0; k < kRSpt; ++k) hx[k] = wrk[k] = 0.0;
-  }
-  int cur_sel_hx = 0, cur_sel_j = 0;
-
+  // ============================= waves 1..7: register-resident samples ===========================================
   for (;;) {
     const int kind = sm.h.req.kind;
     if (kind == RQ_DONE) break;
-    const PassUniforms<MODEL> &u = su;
-
-    if constexpr (METHOD == 0) {  // commit what the machine decided about the previous trial (speculative protocol)
-      if (sm.h.req.sel_j != cur_sel_j) {  // adopt the Broyden update J += ((wrk - hx - J Dp)/||Dp||^2) Dp^T, lm_core.c:760-766
-        const double rinv = 1.0 / dp_prev[kM];
-#pragma unroll
-        for (int k = 0; k < kRSpt; ++k) if (k < nk) {
-          const int s = k * kRWorkers + wt;
-          const double jo[kM] = {jl[s], jl[kRCap + s], jl[2 * kRCap + s]};
-          double t = 0.0;
-#pragma unroll
-          for (int l = 0; l < kM; ++l) t += jo[l] * dp_prev[l];
-          t = div_by(wrk[k] - hx[k] - t, dp_prev[kM], rinv);
-#pragma unroll
-          for (int j = 0; j < kM; ++j) jl[j * kRCap + s] = jo[j] + t * dp_prev[j];
-        }
-        cur_sel_j = sm.h.req.sel_j;
-      }
-      if (sm.h.req.sel_hx != cur_sel_hx) {  // step accepted: hx <- f(p + Dp)
-#pragma unroll
-        for (int k = 0; k < kRSpt; ++k) hx[k] = wrk[k];
-        cur_sel_hx = sm.h.req.sel_hx;
-      }
-    }
-
+    bool pend;
+    decisions(rs, pend);
     double acc[kSums];
 #pragma unroll
     for (int k = 0; k < kSums; ++k) acc[k] = 0.0;
     double mx = 0.0;
-    switch (kind) {
-    case RQ_EVAL:  // (the four kinds only dlevmar_bc_dif / bc_der issue are compiled into those kernels only)
-      if constexpr (METHOD != 0) {
-#pragma unroll
-      for (int k = 0; k < kRSpt; ++k) if (k < nk) {
-        const double f = model_value<MODEL, FAST>(u, s0[k], pq[k]);
-        const double e = (okm >> k & 1u) ? sx[k] - f : 0.0;
-        acc[0] = fma(e, e, acc[0]);
-        mx = fmax(mx, fabs(e));
-      }
-      worker_reduce<1>(acc, mx, red, sums);
-      }
-      break;
-    case RQ_SCALED:
-      if constexpr (METHOD != 0) {
-#pragma unroll
-      for (int k = 0; k < kRSpt; ++k) if (k < nk) {
-        const double f = model_value<MODEL, FAST>(u, s0[k], pq[k]);
-        const double t = (okm >> k & 1u) ? (sx[k] - f) / u.scal : 0.0;
-        acc[0] = fma(t, t, acc[0]);
-      }
-      worker_reduce<1>(acc, mx, red, sums);
-      }
-      break;
-    case RQ_EVAL_MULTI:
-      if constexpr (METHOD != 0) {
-#pragma unroll
-      for (int k = 0; k < kRSpt; ++k) if (k < nk) {
-#pragma unroll
-        for (int j = 0; j < kMaxCand; ++j)
-          if (j < u.ncand) {
-            const double e = (okm >> k & 1u) ? sx[k] - model_value_k<MODEL, FAST>(u, j, s0[k], pq[k]) : 0.0;
-            acc[j] = fma(e, e, acc[j]);
-          }
-      }
-      worker_reduce<kMaxCand>(acc, mx, red, sums);
-      }
-      break;
-    case RQ_JAC:
-      if constexpr (METHOD != 0) {
-#pragma unroll
-      for (int k = 0; k < kRSpt; ++k) if (k < nk) {
-        double f0 = 0.0, j[kM];
-        if (u.analytic)  // dlevmar_bc_der with the model's analytic Jacobian
-          model_an_row<MODEL, FAST>(u, s0[k], pq[k], f0, j);
-        else
-          model_fd_row<MODEL, FAST>(u, s0[k], pq[k], true, f0, 0.0, false, j);
-        double e = sx[k] - f0;
-        if (!(okm >> k & 1u)) e = j[0] = j[1] = j[2] = 0.0;
-        acc_normal_eq_fma(j, e, acc, acc + kNL);
-        acc[kNL + kM] = fma(e, e, acc[kNL + kM]);
-      }
-      worker_reduce<SumLayout<kM>::JAC>(acc, mx, red, sums);
-      }
-      break;
-    case RQ_DIF_INIT:
-      if constexpr (METHOD == 0) {
-#pragma unroll
-        for (int k = 0; k < kRSpt; ++k) if (k < nk) {
-          hx[k] = model_value<MODEL, FAST>(u, s0[k], pq[k]);
-          const double e = (okm >> k & 1u) ? sx[k] - hx[k] : 0.0;
-          acc[0] = fma(e, e, acc[0]);
-        }
-        worker_reduce<1>(acc, mx, red, sums);
-      }
-      break;
-    case RQ_DIF_JAC:
-      if constexpr (METHOD == 0) {
-#pragma unroll
-        for (int k = 0; k < kRSpt; ++k) if (k < nk) {
-          const int s = k * kRWorkers + wt;
-          double f0 = 0.0, j[kM];
-          model_fd_row<MODEL, FAST>(u, s0[k], pq[k], false, f0, hx[k], true, j);
-          double e = sx[k] - hx[k];
-          if (!(okm >> k & 1u)) e = j[0] = j[1] = j[2] = 0.0;
-          jl[s] = j[0];
-          jl[kRCap + s] = j[1];
-          jl[2 * kRCap + s] = j[2];
-          acc_normal_eq_fma(j, e, acc, acc + kNL);
-        }
-        worker_reduce<SumLayout<kM>::DIF_JAC>(acc, mx, red, sums);
-      }
-      break;
-    case RQ_DIF_TRIAL:  // speculative protocol: the Broyden-updated row is formed for the sums only; J itself is
-                        // updated (from wrk, hx) at the top of the next pass if the machine adopts it
-      if constexpr (METHOD == 0) {
-        const double rinv = 1.0 / u.dp_l2;
-#pragma unroll
-        for (int k = 0; k < kRSpt; ++k) if (k < nk) {
-          const int s = k * kRWorkers + wt;
-          const double w = model_value_q<MODEL, FAST>(u, s0[k], pq[k]);
-          const double jo[kM] = {jl[s], jl[kRCap + s], jl[2 * kRCap + s]};
-          double t = 0.0, jn[kM];  // broyden_row() with the division by ||Dp||^2 done by div_by()
-#pragma unroll
-          for (int l = 0; l < kM; ++l) t += jo[l] * u.dp[l];
-          t = div_by(w - hx[k] - t, u.dp_l2, rinv);
-#pragma unroll
-          for (int j = 0; j < kM; ++j) jn[j] = jo[j] + t * u.dp[j];
-          double en = sx[k] - w, eo = sx[k] - hx[k];
-          if (!(okm >> k & 1u)) en = eo = jn[0] = jn[1] = jn[2] = 0.0;
-          wrk[k] = w;
-          acc[0] = fma(en, en, acc[0]);
-          acc_normal_eq_fma(jn, en, acc + 1, acc + 1 + kNL);
-          acc[1 + kNL + kM + 0] = fma(jn[0], eo, acc[1 + kNL + kM + 0]);
-          acc[1 + kNL + kM + 1] = fma(jn[1], eo, acc[1 + kNL + kM + 1]);
-          acc[1 + kNL + kM + 2] = fma(jn[2], eo, acc[1 + kNL + kM + 2]);
-        }
-        worker_reduce<SumLayout<kM>::DIF_TRIAL>(acc, mx, red, sums);
-      }
-      break;
-    default:  // unknown request: keep the barrier protocol, the control wave will not survive it either
-      worker_reduce<1>(acc, mx, red, sums);
-      break;
-    }
+    const double dpp[kM] = {dp_prev[0], dp_prev[1], dp_prev[2]};
+    sweep_pass<MODEL, METHOD, FAST>(kind, su, rs, jl, tid, nk, okm, pend, dpp, acc, mx);
+    reduce_pass<METHOD>(kind, acc, mx, red, sums);
     __syncthreads();  // B: the control wave has stepped the machine
     if (s_abort) return;
   }
@@ -630,7 +777,9 @@ struct RWorkspace {
   static constexpr size_t kMachineBytes = 4096;
   static constexpr size_t off_machine = sizeof(ResidentCtl);
   static constexpr size_t off_rows = off_machine + kMachineBytes;
-  static constexpr size_t rows_bytes = sizeof(u64) * 2 * (size_t)kRowWords * (kRowStride + 16);  // rows + group rows
+  static constexpr size_t rows_bytes = sizeof(u64) * (kRowsGranules + kGroupsGranules);  // rows + group rows
+  static constexpr size_t trace_bytes = sizeof(long long) * 8 * kRowStride;
+  long long h_trace[8 * kRowStride] = {0};
   unsigned tag_base = 0;
   FitStats stats{};
 
@@ -640,8 +789,8 @@ struct RWorkspace {
     hipDeviceProp_t prop;
     HIP_OK(hipGetDeviceProperties(&prop, dev));
     cus = prop.multiProcessorCount;
-    HIP_OK(hipMalloc(&d_block, off_rows + rows_bytes));
-    HIP_OK(hipMemset(d_block, 0, off_rows + rows_bytes));
+    HIP_OK(hipMalloc(&d_block, off_rows + rows_bytes + trace_bytes));
+    HIP_OK(hipMemset(d_block, 0, off_rows + rows_bytes + trace_bytes));
     tag_base = 0;
     HIP_OK(hipHostMalloc(&h_block, off_rows, hipHostMallocDefault));
     HIP_OK(hipHostMalloc(&h_mbox, sizeof(Mailbox), hipHostMallocMapped | hipHostMallocCoherent));
@@ -704,13 +853,22 @@ int resident_attempt(const StreamFitArgs &a, RWorkspace &ws, bool *retry_exact, 
   c.x = a.d_x;
   c.ctl = reinterpret_cast<ResidentCtl *>(ws.d_block);
   c.rows = reinterpret_cast<u64 *>(ws.d_block + RWorkspace::off_rows);
-  c.groups = c.rows + 2 * (size_t)kRowWords * kRowStride;
+  c.groups = c.rows + kRowsGranules;
   c.machine0 = ws.d_block + RWorkspace::off_machine;
   c.mbox = ws.d_mbox;
   c.n = a.n;
   c.tag_base = ws.tag_base;
   c.spin_ticks = kSpinBudgetTicks;
   c.sabotage_epoch = -1;
+  c.replicas = kReplicas;
+  c.trace = nullptr;
+  c.trace_epoch = -1;
+#ifdef BRDF_STAMPS
+  c.trace = reinterpret_cast<long long *>(ws.d_block + RWorkspace::off_rows + RWorkspace::rows_bytes);
+  c.trace_epoch = 20;
+  if (const char *e = getenv("BRDF_HIP_RESIDENT_TRACE_EPOCH")) c.trace_epoch = atoi(e);
+#endif
+  if (const char *e = getenv("BRDF_HIP_RESIDENT_REPLICAS")) c.replicas = std::min(kReplicas, std::max(1, atoi(e)));
   if (const char *e = getenv("BRDF_HIP_RESIDENT_SPIN_MS")) c.spin_ticks = std::max(1LL, atoll(e)) * 100000LL;
   if (const char *e = getenv("BRDF_HIP_RESIDENT_SABOTAGE")) c.sabotage_epoch = atoi(e);  // tests only: forces the fallback
 
@@ -734,6 +892,9 @@ int resident_attempt(const StreamFitArgs &a, RWorkspace &ws, bool *retry_exact, 
     return 0;
   }
   ws.tag_base += (unsigned)mb.passes + 2u;
+#ifdef BRDF_STAMPS
+  (void)hipMemcpy(ws.h_trace, c.trace, RWorkspace::trace_bytes, hipMemcpyDeviceToHost);
+#endif
   if (FAST && mb.domain_bad) {
     *retry_exact = true;
     return 0;
@@ -772,6 +933,11 @@ int resident_run_mm(const StreamFitArgs &a, RWorkspace &ws, bool *unavailable) {
 }  // namespace
 
 FitStats resident_fit_last_stats() { return g_rws.stats; }
+int resident_fit_last_trace(long long *out, int max_rows) {
+  const int rows = std::min(max_rows, kRowStride);
+  memcpy(out, g_rws.h_trace, sizeof(long long) * 8 * (size_t)rows);
+  return rows;
+}
 
 namespace {
 template <int MODEL, int METHOD>
@@ -792,10 +958,12 @@ int resident_batch_mm(bool fast, const BatchCtx &c, hipStream_t stream) {
 
 int resident_batch_enqueue(int model, int method, bool fast, const BatchCtx &c, hipStream_t stream) {
   switch (model * 2 + method) {
+#ifndef BRDF_DEV_WARD_ONLY
   case 0: return resident_batch_mm<0, 0>(fast, c, stream);
   case 1: return resident_batch_mm<0, 1>(fast, c, stream);
   case 2: return resident_batch_mm<1, 0>(fast, c, stream);
   case 3: return resident_batch_mm<1, 1>(fast, c, stream);
+#endif
   case 4: return resident_batch_mm<2, 0>(fast, c, stream);
   default: return resident_batch_mm<2, 1>(fast, c, stream);
   }
@@ -816,12 +984,14 @@ bool resident_fit_try(const StreamFitArgs &a, int *ret) {
   bool unavailable = false;
   int r;
   switch (a.model * 3 + a.method) {
+#ifndef BRDF_DEV_WARD_ONLY
   case 0: r = resident_run_mm<0, 0>(a, ws, &unavailable); break;
   case 1: r = resident_run_mm<0, 1>(a, ws, &unavailable); break;
   case 2: r = resident_run_mm<0, 2>(a, ws, &unavailable); break;
   case 3: r = resident_run_mm<1, 0>(a, ws, &unavailable); break;
   case 4: r = resident_run_mm<1, 1>(a, ws, &unavailable); break;
   case 5: r = resident_run_mm<1, 2>(a, ws, &unavailable); break;
+#endif
   case 6: r = resident_run_mm<2, 0>(a, ws, &unavailable); break;
   case 7: r = resident_run_mm<2, 1>(a, ws, &unavailable); break;
   default: r = resident_run_mm<2, 2>(a, ws, &unavailable); break;

@@ -85,6 +85,7 @@ FitStats stream_fit_last_stats();
 // resident single-launch regime (resident_fit.hip): true if it handled the fit
 bool resident_fit_try(const StreamFitArgs &a, int *ret);
 FitStats resident_fit_last_stats();
+int resident_fit_last_trace(long long *out, int max_rows);  // diagnostic builds: [workgroup][8] stamps of one epoch
 
 int capture_fit_single_run(int model, const unsigned char *d_images, int L, int H, int W, const int *d_pixel_map,
                            const double *d_vertices, const int *d_faces, const double *d_normals, int nf, const double *leds,

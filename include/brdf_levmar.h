@@ -208,6 +208,8 @@ long long brdf_hip_last_fit_launches(void);
  * kernel (launch chain: load state, fold, step, uniforms, persist, sweep, reduce; resident regime: -, sweep +
  * reduce, level-1 gather, level-2 gather + fold, step + uniforms), summed over the fit's passes. */
 int brdf_hip_last_fit_stamps(long long *out8);
+/* diagnostic builds only: [workgroup][8] s_memrealtime stamps / counters of one LM evaluation of the last resident fit; returns rows */
+int brdf_hip_last_fit_trace(long long *out, int max_rows);
 
 #ifdef __cplusplus
 }

@@ -5,8 +5,9 @@ import brdf_amd
 from brdf_amd import synth
 dev = torch.device("cuda:0")
 names = ["load", "fold", "step", "uniforms", "persist", "sweep", "reduce"]           # launch chain (stream_fit.hip)
-names_res = ["-", "sweep+reduce", "gather", "fold", "step+build", "-", "-"]   # resident regime, control wave view (resident_fit.hip)
-for model, n in [(2, 4096), (2, 1_000_000), (1, 1_000_000)]:
+names_res = ["-", "reduce+wait", "publish+level1", "level2+fold", "step+build", "own_sweep", "-"]   # resident regime, control wave view (resident_fit.hip)
+cases = [(2, 4096), (2, 1_000_000)] if os.environ.get("BRDF_STAMPS_WARD_ONLY") else [(2, 4096), (2, 1_000_000), (1, 1_000_000)]
+for model, n in cases:
     angles, x, _ = synth.make_single(model, n)
     a = torch.from_numpy(angles).to(dev); xd = torch.from_numpy(x).to(dev)
     for method in (0, 1):
@@ -16,3 +17,14 @@ for model, n in [(2, 4096), (2, 1_000_000), (1, 1_000_000)]:
         P = max(1, st['passes'] - 1)
         print(model, n, method, r.ret, 'us/pass %.2f' % (st['device_us'] / st['passes']),
               'launches', st['launches'], ' '.join(f"{nm}={out[k]/P:.0f}" for k, nm in enumerate(names_res if st['launches'] == 1 else names)), 'cycles/pass', flush=True)
+        if st['launches'] == 1 and n > 100000:  # one epoch's timeline of every workgroup (s_memrealtime, 10 ns ticks)
+            tr = (C.c_longlong * (8 * 256))(); rows = brdf_amd.lib.brdf_hip_last_fit_trace(tr, 256)
+            t = np.array(tr[:], dtype=np.int64).reshape(256, 8)
+            if t[:, 0].min() > 0:
+                t0 = t[:, 0].min()
+                lead = t[:, 6] > 0
+                for k, nm in enumerate(["pass start", "own sweep done", "reduced (X2)", "published (+level 1 for leaders)", "level 2 gathered", "stepped"]):
+                    v = (t[:, k] - t0) * 0.01
+                    print(f"    trace {nm:34s} us after the first workgroup's pass start: min {v.min():6.2f} median {np.median(v):6.2f} max {v.max():6.2f}"
+                          + (f" | leaders: min {v[lead].min():6.2f} max {v[lead].max():6.2f}" if k == 3 and lead.any() else ""), flush=True)
+                print(f"    trace polls: level 1 (leaders) {sorted(t[lead, 6].tolist())}  level 2 min {t[:, 7].min()} median {int(np.median(t[:, 7]))} max {t[:, 7].max()}", flush=True)
