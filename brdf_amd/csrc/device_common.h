@@ -45,6 +45,23 @@ __device__ __forceinline__ double wave_reduce_to_last(double v) {
   return v;
 }
 
+// two independent reductions side by side (the six steps of one tree are a dependent chain: interleaving two fills it)
+template <class OPA, class OPB>
+__device__ __forceinline__ void wave_reduce2_to_last(double &a, double &b) {
+  a = OPA::apply(a, dpp_move<0x111, 0xf, 0xf>(a, OPA::id()));
+  b = OPB::apply(b, dpp_move<0x111, 0xf, 0xf>(b, OPB::id()));
+  a = OPA::apply(a, dpp_move<0x112, 0xf, 0xf>(a, OPA::id()));
+  b = OPB::apply(b, dpp_move<0x112, 0xf, 0xf>(b, OPB::id()));
+  a = OPA::apply(a, dpp_move<0x114, 0xf, 0xf>(a, OPA::id()));
+  b = OPB::apply(b, dpp_move<0x114, 0xf, 0xf>(b, OPB::id()));
+  a = OPA::apply(a, dpp_move<0x118, 0xf, 0xf>(a, OPA::id()));
+  b = OPB::apply(b, dpp_move<0x118, 0xf, 0xf>(b, OPB::id()));
+  a = OPA::apply(a, dpp_move<0x142, 0xa, 0xf>(a, OPA::id()));
+  b = OPB::apply(b, dpp_move<0x142, 0xa, 0xf>(b, OPB::id()));
+  a = OPA::apply(a, dpp_move<0x143, 0xc, 0xf>(a, OPA::id()));
+  b = OPB::apply(b, dpp_move<0x143, 0xc, 0xf>(b, OPB::id()));
+}
+
 // reduction over one DPP row (16 lanes); result valid in the row's last lane (15, 31, 47, 63)
 template <class OP>
 __device__ __forceinline__ double row_reduce_to_last(double v) {

@@ -416,8 +416,12 @@ struct DifMachine {
     LM_STAMP(0);
     for (;;) {
       if (ONE_LANE) ph = lm_uniform(ph);  // re-assert uniformity: assignments under (formally) divergent branches lose it
-      switch (ph) {
-      case D_INIT_EVAL:  // lm_core.c:551-564
+      // (an ordered chain of guarded blocks, not a switch: see BcMachine::run)
+      if (ph <= 0 || ph >= D_DONE) {
+        req.kind = RQ_DONE;
+        { h.phase = ph; return; }
+      }
+      LM_PHASE(D_INIT_EVAL) {  // lm_core.c:551-564
         h.nfev = 1;
         h.p_e2 = s[0];
         cool.init_e2 = h.p_e2;
@@ -425,8 +429,101 @@ struct DifMachine {
         h.nu = 20;
         ph = D_ITER_TOP;
         break;
+      } LM_PHASE_END
 
-      case D_ITER_TOP:
+      LM_PHASE(D_AFTER_JAC) {
+        unpack_lower<M>(s, h.jtj);
+        for (int i = 0; i < M; ++i) h.jte[i] = s[SumLayout<M>::NL + i];
+        h.newjac = 0;
+        gradient_stats(h, cool);
+        ph = D_SOLVE;
+        break;
+      } LM_PHASE_END
+
+      LM_PHASE(D_AFTER_TRIAL) {  // lm_core.c:742-790
+        h.pdp_e2 = s[0];
+        if (!lm_finite(h.pdp_e2)) {
+          h.stop = 7;
+          ph = D_FINISH;
+          break;
+        }
+        const double dF = h.p_e2 - h.pdp_e2;
+        const bool updated = (h.updp || dF > 0);
+        double dL = 0.0;
+        for (int i = 0; i < M; ++i) dL += h.dp[i] * (h.mu * h.dp[i] + h.jte[i]);
+        h.accepted = (dL > 0.0 && dF > 0.0) ? 1 : 0;
+        if (h.accepted) {  // damping update uses dF, dL of this step: do it now, they are not kept
+          double t = (2.0 * dF / dL - 1.0);
+          t = 1.0 - t * t * t;
+          h.mu = h.mu * ((t >= kOneThird) ? t : kOneThird);
+        }
+        if (updated) {
+          ++h.updjac;
+          h.newjac = 1;
+          if (c.speculative) {  // adopt the speculatively updated Jacobian; keep its products, paired with the
+                                // residual that stays live -- they replace jtj/jte at the top of the next
+                                // iteration, as in the reference
+            h.sel_j ^= 1;
+            unpack_lower<M>(s + 1, cool.spec_jtj);
+            const double *g = s + 1 + SumLayout<M>::NL + (h.accepted ? 0 : M);
+            for (int i = 0; i < M; ++i) cool.spec_jte[i] = g[i];
+          } else {
+            clear_req(h, req);
+            req.kind = RQ_DIF_UPDATE;
+            req.aux = h.accepted;
+            for (int i = 0; i < M; ++i) {
+              req.p[i] = h.p[i];
+              req.q[i] = cool.pdp[i];
+              req.dp[i] = h.dp[i];
+            }
+            req.dp_l2 = h.dp_l2;
+            ph = D_AFTER_UPDATE;
+            { h.phase = ph; return; }
+          }
+        }
+        LM_STAMP(1);
+        ph = D_DECIDE;
+        break;
+      } LM_PHASE_END
+
+      LM_PHASE(D_AFTER_UPDATE) {
+        unpack_lower<M>(s, cool.spec_jtj);
+        for (int i = 0; i < M; ++i) cool.spec_jte[i] = s[SumLayout<M>::NL + i];
+        ph = D_DECIDE;
+        break;
+      } LM_PHASE_END
+
+      LM_PHASE(D_DECIDE) {
+        if (h.accepted) {
+          h.nu = 2;
+          for (int i = 0; i < M; ++i) h.p[i] = cool.pdp[i];
+          if (c.speculative) h.sel_hx ^= 1;  // e, hx <- trial values
+          h.p_e2 = h.pdp_e2;
+          h.updp = 1;
+          ++h.k;
+          ph = D_ITER_TOP;
+          break;
+        }
+        ph = D_REJECT;
+        break;
+      } LM_PHASE_END
+
+      LM_PHASE(D_REJECT) {  // lm_core.c:797-806
+        h.mu *= h.nu;
+        const int nu2 = (int)((unsigned)h.nu << 1);
+        if (nu2 <= h.nu) {
+          h.stop = 5;
+          ph = D_FINISH;
+          break;
+        }
+        h.nu = nu2;
+        for (int i = 0; i < M; ++i) h.jtj[i * M + i] = cool.diag[i];
+        ++h.k;
+        ph = D_ITER_TOP;
+        break;
+      } LM_PHASE_END
+
+      LM_PHASE(D_ITER_TOP) {
         if (!(h.k < c.itmax && !h.stop)) {
           ph = D_FINISH;
           break;
@@ -453,16 +550,10 @@ struct DifMachine {
         }
         ph = D_GRADIENT;
         break;
+      } LM_PHASE_END
 
-      case D_AFTER_JAC:
-        unpack_lower<M>(s, h.jtj);
-        for (int i = 0; i < M; ++i) h.jte[i] = s[SumLayout<M>::NL + i];
-        h.newjac = 0;
-        gradient_stats(h, cool);
-        ph = D_SOLVE;
-        break;
-
-      case D_GRADIENT:
+      LM_PHASE(D_GRADIENT) {
+        LM_STAMP(5);
         if (h.newjac) {  // lm_core.c:590-664 with the sums the trial pass produced for the updated J
           h.newjac = 0;
           for (int i = 0; i < M * M; ++i) h.jtj[i] = cool.spec_jtj[i];
@@ -471,8 +562,9 @@ struct DifMachine {
         }
         ph = D_SOLVE;
         break;
+      } LM_PHASE_END
 
-      case D_SOLVE: {
+      LM_PHASE(D_SOLVE) {
         LM_STAMP(2);
         if (h.jte_inf <= c.o.eps1) {  // lm_core.c:676-680
           h.dp_l2 = 0.0;
@@ -522,90 +614,9 @@ struct DifMachine {
         ph = D_AFTER_TRIAL;
         LM_STAMP(4);
         { h.phase = ph; return; }
-      }
+      } LM_PHASE_END
 
-      case D_AFTER_TRIAL: {  // lm_core.c:742-790
-        h.pdp_e2 = s[0];
-        if (!lm_finite(h.pdp_e2)) {
-          h.stop = 7;
-          ph = D_FINISH;
-          break;
-        }
-        const double dF = h.p_e2 - h.pdp_e2;
-        const bool updated = (h.updp || dF > 0);
-        double dL = 0.0;
-        for (int i = 0; i < M; ++i) dL += h.dp[i] * (h.mu * h.dp[i] + h.jte[i]);
-        h.accepted = (dL > 0.0 && dF > 0.0) ? 1 : 0;
-        if (h.accepted) {  // damping update uses dF, dL of this step: do it now, they are not kept
-          double t = (2.0 * dF / dL - 1.0);
-          t = 1.0 - t * t * t;
-          h.mu = h.mu * ((t >= kOneThird) ? t : kOneThird);
-        }
-        if (updated) {
-          ++h.updjac;
-          h.newjac = 1;
-          if (c.speculative) {  // adopt the speculatively updated Jacobian; keep its products, paired with the
-                                // residual that stays live -- they replace jtj/jte at the top of the next
-                                // iteration, as in the reference
-            h.sel_j ^= 1;
-            unpack_lower<M>(s + 1, cool.spec_jtj);
-            const double *g = s + 1 + SumLayout<M>::NL + (h.accepted ? 0 : M);
-            for (int i = 0; i < M; ++i) cool.spec_jte[i] = g[i];
-          } else {
-            clear_req(h, req);
-            req.kind = RQ_DIF_UPDATE;
-            req.aux = h.accepted;
-            for (int i = 0; i < M; ++i) {
-              req.p[i] = h.p[i];
-              req.q[i] = cool.pdp[i];
-              req.dp[i] = h.dp[i];
-            }
-            req.dp_l2 = h.dp_l2;
-            ph = D_AFTER_UPDATE;
-            { h.phase = ph; return; }
-          }
-        }
-        LM_STAMP(1);
-        ph = D_DECIDE;
-        break;
-      }
-
-      case D_AFTER_UPDATE:
-        unpack_lower<M>(s, cool.spec_jtj);
-        for (int i = 0; i < M; ++i) cool.spec_jte[i] = s[SumLayout<M>::NL + i];
-        ph = D_DECIDE;
-        break;
-
-      case D_DECIDE:
-        if (h.accepted) {
-          h.nu = 2;
-          for (int i = 0; i < M; ++i) h.p[i] = cool.pdp[i];
-          if (c.speculative) h.sel_hx ^= 1;  // e, hx <- trial values
-          h.p_e2 = h.pdp_e2;
-          h.updp = 1;
-          ++h.k;
-          ph = D_ITER_TOP;
-          break;
-        }
-        ph = D_REJECT;
-        break;
-
-      case D_REJECT: {  // lm_core.c:797-806
-        h.mu *= h.nu;
-        const int nu2 = (int)((unsigned)h.nu << 1);
-        if (nu2 <= h.nu) {
-          h.stop = 5;
-          ph = D_FINISH;
-          break;
-        }
-        h.nu = nu2;
-        for (int i = 0; i < M; ++i) h.jtj[i * M + i] = cool.diag[i];
-        ++h.k;
-        ph = D_ITER_TOP;
-        break;
-      }
-
-      case D_FINISH: {  // lm_core.c:809-841
+      LM_PHASE(D_FINISH) {  // lm_core.c:809-841
         if (h.k >= c.itmax) h.stop = 3;
         for (int i = 0; i < M; ++i) h.jtj[i * M + i] = cool.diag[i];
         c.info[0] = cool.init_e2;
@@ -626,12 +637,7 @@ struct DifMachine {
         clear_req(h, req);
         ph = D_DONE;
         { h.phase = ph; return; }
-      }
-
-      default:
-        req.kind = RQ_DONE;
-        { h.phase = ph; return; }
-      }
+      } LM_PHASE_END
     }
   }
 };
@@ -1449,34 +1455,21 @@ struct DerMachine {
     int ph = ONE_LANE ? lm_uniform(h.phase) : h.phase;
     for (;;) {
       if (ONE_LANE) ph = lm_uniform(ph);  // re-assert uniformity: assignments under (formally) divergent branches lose it
-      switch (ph) {
-      case R_INIT_EVAL:  // lm_core.c:168-179
+      // (an ordered chain of guarded blocks, not a switch: see BcMachine::run)
+      if (ph <= 0 || ph >= R_DONE) {
+        req.kind = RQ_DONE;
+        { h.phase = ph; return; }
+      }
+      LM_PHASE(R_INIT_EVAL) {  // lm_core.c:168-179
         h.nfev = 1;
         h.p_e2 = s[0];
         h.init_e2 = h.p_e2;
         if (!lm_finite(h.p_e2)) h.stop = 7;
         ph = R_ITER_TOP;
         break;
+      } LM_PHASE_END
 
-      case R_ITER_TOP:
-        if (!(h.k < c.itmax && !h.stop)) {
-          ph = R_FINISH;
-          break;
-        }
-        if (h.p_e2 <= c.o.eps3) {
-          h.stop = 6;
-          ph = R_FINISH;
-          break;
-        }
-        clear_req(h, req);
-        req.kind = RQ_JAC;
-        for (int i = 0; i < M; ++i) req.p[i] = h.p[i];
-        ++h.njev;
-        ph = R_AFTER_JAC;
-        h.phase = ph;
-        return;
-
-      case R_AFTER_JAC: {  // lm_core.c:262-291
+      LM_PHASE(R_AFTER_JAC) {  // lm_core.c:262-291
         unpack_lower<M>(s, h.jtj);
         for (int i = 0; i < M; ++i) h.jte[i] = s[SumLayout<M>::NL + i];
         h.p_l2 = h.jte_inf = 0.0;
@@ -1500,9 +1493,44 @@ struct DerMachine {
         }
         ph = R_SOLVE;
         break;
-      }
+      } LM_PHASE_END
 
-      case R_SOLVE: {  // the inner while(1), lm_core.c:294-397
+      LM_PHASE(R_AFTER_EVAL) {  // lm_core.c:347-396
+        h.pdp_e2 = s[0];
+        if (!lm_finite(h.pdp_e2)) {
+          h.stop = 7;
+          ph = R_END_ITER;
+          break;
+        }
+        double dL = 0.0;
+        for (int i = 0; i < M; ++i) dL += h.dp[i] * (h.mu * h.dp[i] + h.jte[i]);
+        const double dF = h.p_e2 - h.pdp_e2;
+        if (dL > 0.0 && dF > 0.0) {
+          double t = (2.0 * dF / dL - 1.0);
+          t = 1.0 - t * t * t;
+          h.mu = h.mu * ((t >= kOneThird) ? t : kOneThird);
+          h.nu = 2;
+          for (int i = 0; i < M; ++i) h.p[i] = h.pdp[i];
+          h.p_e2 = h.pdp_e2;
+          ph = R_END_ITER;
+          break;
+        }
+        h.mu *= h.nu;
+        {
+          const int nu2 = (int)((unsigned)h.nu << 1);
+          if (nu2 <= h.nu) {
+            h.stop = 5;
+            ph = R_END_ITER;
+            break;
+          }
+          h.nu = nu2;
+        }
+        for (int i = 0; i < M; ++i) h.jtj[i * M + i] = h.diag[i];
+        ph = R_SOLVE;
+        break;
+      } LM_PHASE_END
+
+      LM_PHASE(R_SOLVE) {  // the inner while(1), lm_core.c:294-397
         for (int i = 0; i < M; ++i) h.jtj[i * M + i] += h.mu;
         const int solved = lu_solve<M>(h.jtj, h.jte, h.dp);
         ++h.nlss;
@@ -1544,49 +1572,34 @@ struct DerMachine {
         }
         for (int i = 0; i < M; ++i) h.jtj[i * M + i] = h.diag[i];
         break;  // solve again
-      }
+      } LM_PHASE_END
 
-      case R_AFTER_EVAL: {  // lm_core.c:347-396
-        h.pdp_e2 = s[0];
-        if (!lm_finite(h.pdp_e2)) {
-          h.stop = 7;
-          ph = R_END_ITER;
-          break;
-        }
-        double dL = 0.0;
-        for (int i = 0; i < M; ++i) dL += h.dp[i] * (h.mu * h.dp[i] + h.jte[i]);
-        const double dF = h.p_e2 - h.pdp_e2;
-        if (dL > 0.0 && dF > 0.0) {
-          double t = (2.0 * dF / dL - 1.0);
-          t = 1.0 - t * t * t;
-          h.mu = h.mu * ((t >= kOneThird) ? t : kOneThird);
-          h.nu = 2;
-          for (int i = 0; i < M; ++i) h.p[i] = h.pdp[i];
-          h.p_e2 = h.pdp_e2;
-          ph = R_END_ITER;
-          break;
-        }
-        h.mu *= h.nu;
-        {
-          const int nu2 = (int)((unsigned)h.nu << 1);
-          if (nu2 <= h.nu) {
-            h.stop = 5;
-            ph = R_END_ITER;
-            break;
-          }
-          h.nu = nu2;
-        }
-        for (int i = 0; i < M; ++i) h.jtj[i * M + i] = h.diag[i];
-        ph = R_SOLVE;
-        break;
-      }
-
-      case R_END_ITER:
+      LM_PHASE(R_END_ITER) {
         ++h.k;
         ph = R_ITER_TOP;
         break;
+      } LM_PHASE_END
 
-      case R_FINISH: {  // lm_core.c:400-431
+      LM_PHASE(R_ITER_TOP) {
+        if (!(h.k < c.itmax && !h.stop)) {
+          ph = R_FINISH;
+          break;
+        }
+        if (h.p_e2 <= c.o.eps3) {
+          h.stop = 6;
+          ph = R_FINISH;
+          break;
+        }
+        clear_req(h, req);
+        req.kind = RQ_JAC;
+        for (int i = 0; i < M; ++i) req.p[i] = h.p[i];
+        ++h.njev;
+        ph = R_AFTER_JAC;
+        h.phase = ph;
+        return;
+      } LM_PHASE_END
+
+      LM_PHASE(R_FINISH) {  // lm_core.c:400-431
         if (h.k >= c.itmax) h.stop = 3;
         for (int i = 0; i < M; ++i) h.jtj[i * M + i] = h.diag[i];
         c.info[0] = h.init_e2;
@@ -1608,13 +1621,7 @@ struct DerMachine {
         ph = R_DONE;
         h.phase = ph;
         return;
-      }
-
-      default:
-        req.kind = RQ_DONE;
-        h.phase = ph;
-        return;
-      }
+      } LM_PHASE_END
     }
   }
 };

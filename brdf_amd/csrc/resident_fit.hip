@@ -47,6 +47,14 @@
 #include <cstring>
 #include <type_traits>
 
+#if defined(BRDF_STAMPS)
+#include <hip/hip_runtime.h>
+__device__ long long g_rlm_stamps[8];  // diagnostic: cycles per section of the machines' run(), workgroup 0 only, summed over passes
+__device__ long long g_rlm_last;
+#endif
+#if defined(BRDF_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+#define LM_STAMP(i) do { if (blockIdx.x == 0) { const long long now_ = clock64(); if ((i) != 0) g_rlm_stamps[i] += now_ - g_rlm_last; g_rlm_last = now_; } } while (0)
+#endif
 #include "batch_fit.h"
 #include "stream_fit.h"
 
@@ -89,13 +97,6 @@ struct ResidentCtx {
 template <int METHOD>
 using RMachine = typename std::conditional<METHOD == 0, DifMachine<kM>, typename std::conditional<METHOD == 1, BcMachine<kM>, DerMachine<kM>>::type>::type;
 
-__device__ __forceinline__ void put_value(u64 *rows, int stride, int word, int col, unsigned tag, double v) {
-  const u64 bits = (u64)__double_as_longlong(v);
-  __hip_atomic_store(rows + (size_t)word * stride + col, ((u64)tag << 32) | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(rows + (size_t)(word + 1) * stride + col, ((u64)tag << 32) | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ u64 get_granule(const u64 *g) { return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ double join_halves(u64 lo, u64 hi) { return __longlong_as_double((long long)((lo & 0xffffffffull) | (hi << 32))); }
 __device__ __forceinline__ double read_lane(double v, int lane) {  // lane is wave-uniform
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
@@ -172,7 +173,7 @@ __device__ __forceinline__ void for_samples(int nk, F &&f) {
 // every 4 consecutive lanes in lanes 3,7,11,..; those park their values as buf[slot][thread/4]; wave w then owns slots
 // {w, w+8}: each lane adds its two entries and one DPP tree per slot finishes it.  A pure function of NS: reproducible.
 template <int NS>
-__device__ __forceinline__ void worker_reduce(const double *acc, double mx, double *buf, double *out) {
+__device__ __forceinline__ void worker_reduce(const double *acc, double mx, double *buf, double *out, long long *st_, long long &last_) {
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;  // 0..7
   double v[NS + 1];
@@ -194,17 +195,32 @@ __device__ __forceinline__ void worker_reduce(const double *acc, double mx, doub
     for (int k = 0; k <= NS; ++k) buf[k * kRedCols + (threadIdx.x >> 2)] = v[k];
   }
   __syncthreads();  // X1
-  for (int k = wave; k <= NS; k += kRThreads / kWave) {  // wave-uniform loop
-    const double *src = buf + k * kRedCols;
-    double s = src[lane];
-    if (k < NS) {
-      s += src[lane + kWave];
-      s = wave_reduce_to_last<OpSum>(s);
-      if (lane == kWave - 1) out[k] = s;
+  RSTAMP(6);
+  {  // wave w finishes slots w and w + 8 (wave-uniform conditions), the two dependent DPP trees interleaved
+    constexpr int NW = kRThreads / kWave;
+    const int k0 = wave, k1 = wave + NW;
+    const bool has0 = k0 <= NS, has1 = k1 <= NS;
+    double s0 = 0.0, s1 = 0.0;
+    if (has0) {
+      const double *src = buf + k0 * kRedCols;
+      s0 = (k0 < NS) ? src[lane] + src[lane + kWave] : fmax(src[lane], src[lane + kWave]);
+    }
+    if (has1) {
+      const double *src = buf + k1 * kRedCols;
+      s1 = (k1 < NS) ? src[lane] + src[lane + kWave] : fmax(src[lane], src[lane + kWave]);
+    }
+    // (the max slot is slot NS: it is the LAST slot of whichever wave owns it, so at most one of the two is a max)
+    const bool max0 = has0 && k0 == NS, max1 = has1 && k1 == NS;
+    if (!max0 && !max1) {
+      wave_reduce2_to_last<OpSum, OpSum>(s0, s1);
+    } else if (max1) {
+      wave_reduce2_to_last<OpSum, OpMax>(s0, s1);
     } else {
-      s = fmax(s, src[lane + kWave]);
-      s = wave_reduce_to_last<OpMax>(s);
-      if (lane == kWave - 1) out[kSums] = s;
+      wave_reduce2_to_last<OpMax, OpSum>(s0, s1);
+    }
+    if (lane == kWave - 1) {
+      if (has0) out[max0 ? kSums : k0] = s0;
+      if (has1) out[max1 ? kSums : k1] = s1;
     }
   }
   __syncthreads();  // X2
@@ -214,57 +230,70 @@ __device__ __forceinline__ void worker_reduce(const double *acc, double mx, doub
 // 256 rows -- was measured at 6.2 us: 256 readers per line make the few hundred lines of the row table a hot spot
 // of the memory side; more loads in flight per reader made it slower, not faster.)
 //
-//   level 1  rows [parity][group][word][member], word = 2*slot + half: workgroups are grouped 16 by 16 and a group's
-//            28 words x 16 members are 3.5 KB of CONSECUTIVE granules.  Every workgroup publishes its NS sums + max
-//            (lanes 0..NS-1 and lane 13, two granules each).  One workgroup of a group is its leader (a different
+//   level 1  rows [parity][group][slot][member]: workgroups are grouped 16 by 16 and a group's 14 slots x 16 members
+//            are 3.5 KB of CONSECUTIVE 16-byte cells.  Every workgroup publishes its NS sums + max (lanes 0..NS-1 and
+//            lane 13, one cell each).  One workgroup of a group is its leader (a different
 //            position in every group, so that the leaders -- blockIdx % 8 tells which workgroups share an XCD -- are spread
 //            over the XCDs).  ALL 64 lanes of its control wave gather: lane l takes member l % 16 of slot 4j + l / 16,
-//            j = 0..3 (a wave load instruction reads 4 whole lines; 8 instructions fetch a TRIAL row set), so the 16
+//            j = 0..3 (a wave load instruction reads 1 KB = 8 whole lines; 4 instructions fetch a TRIAL row set), so the 16
 //            members of a slot sit in one DPP row and four row reductions (fixed order) fold everything.  (The first
 //            version kept ONE table [word][256 workgroups]: a leader's 16 active lanes issued 28 loads, 2 KB apart, per
 //            attempt, and an attempt took ~1.5 us -- the in-kernel trace showed level 1 alone at 3.4 us.)
-//   level 2  groups [parity][replica][word][group]: the leader broadcasts each folded value inside its DPP row
+//   level 2  groups [parity][replica][slot][group]: the leader broadcasts each folded value inside its DPP row
 //            (row_newbcast) and lanes 0..replicas-1 of the row store one copy each, so that a line is polled by #CUs /
 //            replicas workgroups instead of all of them (one copy: +0.9 us).  Every workgroup (leaders too) gathers the
 //            <= 16 group rows of copy blockIdx % replicas the same way and folds them: identical bits everywhere.
 //
 // A gather re-reads its block until every tag matches; false = wait abandoned (spin budget, or somebody else gave up).
 constexpr int kGroup = 16;
-constexpr int kMaxGroups = 16;  // >= ceil(#CUs / kGroup); also the width of a level-2 row: one 128-B line
+constexpr int kMaxGroups = 16;  // >= ceil(#CUs / kGroup); also the width of a level-2 row
 constexpr int kReplicas = 8;
 constexpr size_t kBlockGranules = (size_t)kRowWords * kGroup;                    // one group's rows / one copy of the group rows
 constexpr size_t kRowsGranules = 2 * (size_t)kMaxGroups * kBlockGranules;         // [parity][group]
 constexpr size_t kGroupsGranules = 2 * (size_t)kReplicas * kBlockGranules;        // [parity][replica]
 
+// A value travels as ONE 16-byte cell = two granules {lo32, tag | hi32, tag}, written by one write-through (sc1) store and
+// read by one sc1 load: a scalar sc1 store is one fabric write whatever its size, so 8-byte stores cost 2.7x the time per
+// byte of 16-byte ones (MI355X_MICROARCH.md, inter-workgroup visibility table) -- a leader publishes up to 14 x 8 cells
+// per pass.  Each half carries its own tag, so a cell torn between its halves is simply "not ready yet".
+// A block is [slot][16 columns] cells.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kCacheSc1 = 16;  // aux bits of the gfx940+ buffer instructions: sc1
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t table_rsrc(const u64 *p, size_t granules) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<u64 *>(p), 0, (int)(granules * sizeof(u64)), 0x00027000);
+}
+__device__ __forceinline__ void put_cell(__amdgpu_buffer_rsrc_t t, unsigned cell, unsigned tag, double v) {
+  const u32x4 d = {(unsigned)__double2loint(v), tag, (unsigned)__double2hiint(v), tag};
+  __builtin_amdgcn_raw_buffer_store_b128(d, t, (int)(cell * 16u), 0, kCacheSc1);
+}
+
 template <int NS>
 __device__ __forceinline__ constexpr bool slot_used(int v) { return v < NS || v == kSums; }
 
-// val[j] <- slot 4j + lane/16 of column lane%16 of the block (0 where the slot is not used or the column >= ncols)
+// val[j] <- slot 4j + lane/16 of column lane%16 of the block starting at cell `first` (0 where the slot is not used or
+// the column >= ncols)
 template <int NS>
-__device__ __forceinline__ bool gather_block(const ResidentCtx &ctx, const u64 *blk, unsigned tag, int ncols, double (&val)[4],
-                                             unsigned *polls) {
+__device__ __forceinline__ bool gather_block(const ResidentCtx &ctx, __amdgpu_buffer_rsrc_t t, unsigned first, unsigned tag, int ncols,
+                                             double (&val)[4], unsigned *polls) {
   const int lane = threadIdx.x;  // control wave = wave 0
   const int col = lane & 15, r = lane >> 4;
   const long long t0 = (long long)wall_clock64();
   for (unsigned spins = 0;; ++spins) {
-    u64 lo[4], hi[4];
+    u32x4 d[4];
     bool ready = true;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      lo[j] = hi[j] = (u64)tag << 32;
+      d[j] = u32x4{0u, tag, 0u, tag};
       if ((4 * j < NS) || (4 * j <= kSums && kSums < 4 * j + 4)) {  // (compile time) some row of this instruction is used
         const int v = 4 * j + r;
-        if (slot_used<NS>(v) && col < ncols) {
-          lo[j] = get_granule(blk + (size_t)(2 * v) * kGroup + col);
-          hi[j] = get_granule(blk + (size_t)(2 * v + 1) * kGroup + col);
-        }
+        if (slot_used<NS>(v) && col < ncols) d[j] = __builtin_amdgcn_raw_buffer_load_b128(t, (int)((first + v * kGroup + col) * 16u), 0, kCacheSc1);
       }
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) ready = ready && (unsigned)(lo[j] >> 32) == tag && (unsigned)(hi[j] >> 32) == tag;
+    for (int j = 0; j < 4; ++j) ready = ready && d[j].y == tag && d[j].w == tag;
     if (__all(ready)) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) val[j] = join_halves(lo[j], hi[j]);
+      for (int j = 0; j < 4; ++j) val[j] = __hiloint2double((int)d[j].z, (int)d[j].x);
       *polls = spins;
       return true;
     }
@@ -298,15 +327,17 @@ __device__ __forceinline__ bool control_exchange(const ResidentCtx &ctx, unsigne
   const int members = min(kGroup, G - grp * kGroup);
   const int leader = grp * kGroup + (grp & 7) % members;
   const unsigned tag = ctx.tag_base + epoch + 1u;
-  u64 *rows = ctx.rows + ((size_t)(epoch & 1u) * kMaxGroups + grp) * kBlockGranules;
-  u64 *groups = ctx.groups + (size_t)(epoch & 1u) * kReplicas * kBlockGranules;
+  constexpr unsigned kBlockCells = kSlots * kGroup;
+  const __amdgpu_buffer_rsrc_t rows = table_rsrc(ctx.rows, kRowsGranules), groups = table_rsrc(ctx.groups, kGroupsGranules);
+  const unsigned my_rows = ((epoch & 1u) * kMaxGroups + grp) * kBlockCells;   // first cell of this group's block
+  const unsigned my_groups = (epoch & 1u) * kReplicas * kBlockCells;           // first cell of copy 0 of the group rows
   const bool withhold = (int)epoch == ctx.sabotage_epoch && blockIdx.x == gridDim.x - 1;  // test hook, see ResidentCtx
-  if (slot_used<NS>(lane) && lane <= kSums && !withhold) put_value(rows, kGroup, 2 * lane, blockIdx.x % kGroup, tag, sums[lane]);
+  if (slot_used<NS>(lane) && lane <= kSums && !withhold) put_cell(rows, my_rows + lane * kGroup + blockIdx.x % kGroup, tag, sums[lane]);
 
   double val[4];
   unsigned polls = 0;
   if ((int)blockIdx.x == leader) {  // group leader (workgroup-uniform branch)
-    if (!gather_block<NS>(ctx, rows, tag, members, val, &polls)) {
+    if (!gather_block<NS>(ctx, rows, my_rows, tag, members, val, &polls)) {
       *s_abort = 1;
       return false;
     }
@@ -316,12 +347,12 @@ __device__ __forceinline__ bool control_exchange(const ResidentCtx &ctx, unsigne
     for (int j = 0; j < 4; ++j) {
       const double t = dpp_move<0x15F, 0xf, 0xf>(val[j], 0.0);  // row_newbcast:15: the row's total in all 16 lanes of the row
       const int v = 4 * j + r;
-      if (slot_used<NS>(v) && col < ctx.replicas) put_value(groups + (size_t)col * kBlockGranules, kGroup, 2 * v, grp, tag, t);
+      if (slot_used<NS>(v) && col < ctx.replicas) put_cell(groups, my_groups + col * kBlockCells + v * kGroup + grp, tag, t);
     }
   }
   RSTAMP(2);
   RTRACE(ctx, epoch, 3, wall_clock64());
-  if (!gather_block<NS>(ctx, groups + (size_t)(blockIdx.x % ctx.replicas) * kBlockGranules, tag, ngrp, val, &polls)) {
+  if (!gather_block<NS>(ctx, groups, my_groups + (blockIdx.x % ctx.replicas) * kBlockCells, tag, ngrp, val, &polls)) {
     *s_abort = 1;
     return false;
   }
@@ -474,18 +505,18 @@ __device__ __forceinline__ void sweep_pass(int kind, const PassUniforms<MODEL> &
 
 // the matching reduction (the number of sums depends on the request kind only: wave-uniform)
 template <int METHOD>
-__device__ __forceinline__ void reduce_pass(int kind, const double *acc, double mx, double *red, double *sums) {
+__device__ __forceinline__ void reduce_pass(int kind, const double *acc, double mx, double *red, double *sums, long long *st_, long long &last_) {
   if constexpr (METHOD == 0) {
     switch (kind) {
-    case RQ_DIF_JAC: worker_reduce<SumLayout<kM>::DIF_JAC>(acc, mx, red, sums); break;
-    case RQ_DIF_TRIAL: worker_reduce<SumLayout<kM>::DIF_TRIAL>(acc, mx, red, sums); break;
-    default: worker_reduce<1>(acc, mx, red, sums); break;
+    case RQ_DIF_JAC: worker_reduce<SumLayout<kM>::DIF_JAC>(acc, mx, red, sums, st_, last_); break;
+    case RQ_DIF_TRIAL: worker_reduce<SumLayout<kM>::DIF_TRIAL>(acc, mx, red, sums, st_, last_); break;
+    default: worker_reduce<1>(acc, mx, red, sums, st_, last_); break;
     }
   } else {
     switch (kind) {
-    case RQ_JAC: worker_reduce<SumLayout<kM>::JAC>(acc, mx, red, sums); break;
-    case RQ_EVAL_MULTI: worker_reduce<kMaxCand>(acc, mx, red, sums); break;
-    default: worker_reduce<1>(acc, mx, red, sums); break;
+    case RQ_JAC: worker_reduce<SumLayout<kM>::JAC>(acc, mx, red, sums, st_, last_); break;
+    case RQ_EVAL_MULTI: worker_reduce<kMaxCand>(acc, mx, red, sums, st_, last_); break;
+    default: worker_reduce<1>(acc, mx, red, sums, st_, last_); break;
     }
   }
 }
@@ -498,6 +529,10 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
   using Machine = RMachine<METHOD>;
   using Mdl = BrdfModel<MODEL>;
   constexpr int NF = sample_fields<METHOD>();
+  // dlevmar_dif: the control wave's 7 x 8 doubles of sample state do not fit next to the LM step's registers: they are
+  // parked in LDS.  The other entry points keep 4 x 8 doubles per lane: registers, like every other wave -- except
+  // dlevmar_bc_dif spread over the grid, where the exchange code on top of the machine's step spilled 56 VGPRs.
+  constexpr bool kControlFromLds = (METHOD == 0) || (METHOD == 1 && !BATCHED);
   static_assert(sizeof(Machine) % 4 == 0, "machine copied as dwords");
   __shared__ Machine sm;
   __shared__ PassUniforms<MODEL> su;
@@ -505,7 +540,7 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
   __shared__ double sums[kSlots];
   __shared__ double dp_prev[kM + 1];  // Dp and ||Dp||^2 of the last trial (dif)
   __shared__ int s_abort, s_bad;
-  __shared__ double cst[NF * kRSpt * kWave];  // the control wave's samples
+  __shared__ double cst[kControlFromLds ? NF * kRSpt * kWave : 2];  // the control wave's samples
   constexpr int kJl = (METHOD == 0) ? 3 * kRCap : 2;
   __shared__ double jl[kJl];  // dif: the secant Jacobian, SoA planes
 
@@ -580,7 +615,7 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
     } else {
       if (FAST && bad) __hip_atomic_store(&ctx.ctl->domain_bad, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (wave == 0) {  // park the control wave's samples in LDS
+    if (kControlFromLds && wave == 0) {  // park the control wave's samples in LDS
 #pragma unroll
       for (int f = 0; f < NF; ++f)
 #pragma unroll
@@ -610,6 +645,21 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
     long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long last_ = clock64();
     long long n_jac = 0;
+    // The machine is stepped where it lives, in LDS.  Two register variants were measured and kept out: a register copy of
+    // the busy half (Machine::Core) made for every step cost more than it saved (170 LDS operations to copy in and out:
+    // 9600 against 8100 cycles per step); keeping Core in this wave's registers for the whole fit (-DBRDF_CORE_IN_REGS; the
+    // sweep runs from LDS with a rolled loop, so the ~90 registers are free) came out even (8170 against 8350 cycles): the
+    // step is a chain of ~1000 dependent fp64 operations on one wave (LM_STAMP sections per step: judging the trial 1070
+    // cycles, decide + iteration top 1780, gradient 940, the 3x3 LU 2300, stop tests + request 1080), not LDS latency.
+    // dlevmar_bc_dif's machine (line search, 8 projected-gradient candidates) does not fit next to its own step code
+    // (160 VGPRs spilled): it always steps in LDS.
+#ifdef BRDF_CORE_IN_REGS
+    constexpr bool kCoreInRegs = METHOD != 1;
+#else
+    constexpr bool kCoreInRegs = false;
+#endif
+    typename Machine::Core hcore = sm.h;
+    if constexpr (kCoreInRegs) Machine::uniform_ints(hcore);
     const long long t_first = (long long)wall_clock64();
     unsigned epoch = 0;
     for (;; ++epoch) {
@@ -619,16 +669,21 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
       RTRACE(ctx, epoch, 0, wall_clock64());
       {
         bool pend;
-        decisions(ls, pend);
         double acc[kSums];
 #pragma unroll
         for (int k = 0; k < kSums; ++k) acc[k] = 0.0;
         double mx = 0.0;
         const double dpp[kM] = {dp_prev[0], dp_prev[1], dp_prev[2]};
-        sweep_pass<MODEL, METHOD, FAST>(kind, su, ls, jl, tid, nk, okm, pend, dpp, acc, mx);
+        if constexpr (kControlFromLds) {
+          decisions(ls, pend);
+          sweep_pass<MODEL, METHOD, FAST>(kind, su, ls, jl, tid, nk, okm, pend, dpp, acc, mx);
+        } else {
+          decisions(rs, pend);
+          sweep_pass<MODEL, METHOD, FAST>(kind, su, rs, jl, tid, nk, okm, pend, dpp, acc, mx);
+        }
         RSTAMP(5);  // the control wave's own sweep
         RTRACE(ctx, epoch, 1, wall_clock64());
-        reduce_pass<METHOD>(kind, acc, mx, red, sums);  // X1, X2: sums[] hold this workgroup's partial sums
+        reduce_pass<METHOD>(kind, acc, mx, red, sums, st_, last_);  // X1, X2: sums[] hold this workgroup's partial sums
       }
       RSTAMP(1);  // reduction + waiting for the slowest wave
       RTRACE(ctx, epoch, 2, wall_clock64());
@@ -668,42 +723,28 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
         for (int j = 0; j < kM; ++j) dp_prev[j] = su.dp[j];
         dp_prev[kM] = su.dp_l2;
       }
-      {  // the LM step on a register copy of the machine's hot half (see the file comment)
-        // The machine is stepped where it lives, in LDS.  Stepping a REGISTER copy of its busy half (Machine::Core; the
-        // machines are laid out for it) was measured and lost: 9600 against 8100 cycles per dlevmar_dif step with 22 VGPRs
-        // spilled, 10600 with 105; dlevmar_bc_dif's machine (line search, 8 projected-gradient candidates) spilled 160 and
-        // ran 30 % slower.  -DBRDF_STEP_IN_REGS builds that variant.
-#ifdef BRDF_STEP_IN_REGS
-        constexpr bool kStepInRegs = METHOD != 1;
-#else
-        constexpr bool kStepInRegs = false;
-#endif
-        if constexpr (!kStepInRegs) {
-          sm.template step<true>(sums, sums[kSums]);
-        } else {
-        typename Machine::Core h = sm.h;  // (the request stays in LDS: the step only writes it)
-#ifndef BRDF_CORE_PLAIN
-        Machine::uniform_ints(h);
-#endif
-        if constexpr (METHOD == 1)
-          Machine::template run<true, true, false>(sm.c, h, sm.h.cool, sm.h.req, sums, sums[kSums], true);
-        else if constexpr (METHOD == 0)
-          Machine::template run<true>(sm.c, h, sm.h.cool, sm.h.req, sums, sums[kSums]);
+      // The LM step.  kCoreInRegs: the machine's busy half (Machine::Core) lives in this wave's REGISTERS for the whole fit
+      // (hcore, loaded before the loop); Cool and the request stay in LDS, where the other waves read the request.
+      if constexpr (kCoreInRegs) {
+        if constexpr (METHOD == 0)
+          Machine::template run<true>(sm.c, hcore, sm.h.cool, sm.h.req, sums, sums[kSums]);
         else
-          Machine::template run<true>(sm.c, h, sm.h.req, sums, sums[kSums]);
-        static_cast<typename Machine::Core &>(sm.h) = h;
-        }
-        if (sm.h.req.kind != RQ_DONE) {
-          if constexpr (METHOD == 1)
-            su.build(sm.h.req, /*need_base=*/false, sm.c.analytic_jac != 0);
-          else
-            su.build(sm.h.req, /*need_base=*/false, METHOD == 2);
-        }
+          Machine::template run<true>(sm.c, hcore, sm.h.req, sums, sums[kSums]);
+      } else {
+        sm.template step<true>(sums, sums[kSums]);
+      }
+      RSTAMP(7);  // the step alone
+      if (sm.h.req.kind != RQ_DONE) {
+        if constexpr (METHOD == 1)
+          su.build(sm.h.req, /*need_base=*/false, sm.c.analytic_jac != 0);
+        else
+          su.build(sm.h.req, /*need_base=*/false, METHOD == 2);
       }
       RTRACE(ctx, epoch, 5, wall_clock64());
       __syncthreads();  // B: the next request and its uniforms are in LDS
       RSTAMP(4);
     }
+    if constexpr (kCoreInRegs) static_cast<typename Machine::Core &>(sm.h) = hcore;
     if constexpr (BATCHED) {
       if (tid == 0) {
         double *po = bctx.p + (size_t)fit * kM;
@@ -738,6 +779,7 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
   }
 
   // ============================= waves 1..7: register-resident samples ===========================================
+  long long wst_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wlast_ = 0;  // (stamps are the control wave's; these are never read)
   for (;;) {
     const int kind = sm.h.req.kind;
     if (kind == RQ_DONE) break;
@@ -749,7 +791,7 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
     double mx = 0.0;
     const double dpp[kM] = {dp_prev[0], dp_prev[1], dp_prev[2]};
     sweep_pass<MODEL, METHOD, FAST>(kind, su, rs, jl, tid, nk, okm, pend, dpp, acc, mx);
-    reduce_pass<METHOD>(kind, acc, mx, red, sums);
+    reduce_pass<METHOD>(kind, acc, mx, red, sums, wst_, wlast_);
     __syncthreads();  // B: the control wave has stepped the machine
     if (s_abort) return;
   }
@@ -779,7 +821,7 @@ struct RWorkspace {
   static constexpr size_t off_rows = off_machine + kMachineBytes;
   static constexpr size_t rows_bytes = sizeof(u64) * (kRowsGranules + kGroupsGranules);  // rows + group rows
   static constexpr size_t trace_bytes = sizeof(long long) * 8 * kRowStride;
-  long long h_trace[8 * kRowStride] = {0};
+  long long h_trace[8 * (kRowStride + 1)] = {0};  // + one row: the sections of the LM step (LM_STAMP)
   unsigned tag_base = 0;
   FitStats stats{};
 
@@ -894,6 +936,11 @@ int resident_attempt(const StreamFitArgs &a, RWorkspace &ws, bool *retry_exact, 
   ws.tag_base += (unsigned)mb.passes + 2u;
 #ifdef BRDF_STAMPS
   (void)hipMemcpy(ws.h_trace, c.trace, RWorkspace::trace_bytes, hipMemcpyDeviceToHost);
+  (void)hipMemcpyFromSymbol(ws.h_trace + 8 * kRowStride, HIP_SYMBOL(g_rlm_stamps), sizeof(long long) * 8);
+  {
+    long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_rlm_stamps), zero, sizeof zero);
+  }
 #endif
   if (FAST && mb.domain_bad) {
     *retry_exact = true;
@@ -934,7 +981,7 @@ int resident_run_mm(const StreamFitArgs &a, RWorkspace &ws, bool *unavailable) {
 
 FitStats resident_fit_last_stats() { return g_rws.stats; }
 int resident_fit_last_trace(long long *out, int max_rows) {
-  const int rows = std::min(max_rows, kRowStride);
+  const int rows = std::min(max_rows, kRowStride + 1);
   memcpy(out, g_rws.h_trace, sizeof(long long) * 8 * (size_t)rows);
   return rows;
 }

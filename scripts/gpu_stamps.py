@@ -5,7 +5,7 @@ import brdf_amd
 from brdf_amd import synth
 dev = torch.device("cuda:0")
 names = ["load", "fold", "step", "uniforms", "persist", "sweep", "reduce"]           # launch chain (stream_fit.hip)
-names_res = ["-", "reduce+wait", "publish+level1", "level2+fold", "step+build", "own_sweep", "-"]   # resident regime, control wave view (resident_fit.hip)
+names_res = ["-", "stage2+X2", "publish+level1", "level2+fold", "build+B", "own_sweep", "stage1+X1wait", "step"]   # resident regime, control wave view (resident_fit.hip)
 cases = [(2, 4096), (2, 1_000_000)] if os.environ.get("BRDF_STAMPS_WARD_ONLY") else [(2, 4096), (2, 1_000_000), (1, 1_000_000)]
 for model, n in cases:
     angles, x, _ = synth.make_single(model, n)
@@ -16,10 +16,12 @@ for model, n in cases:
         out = (C.c_longlong * 8)(); brdf_amd.lib.brdf_hip_last_fit_stamps(out)
         P = max(1, st['passes'] - 1)
         print(model, n, method, r.ret, 'us/pass %.2f' % (st['device_us'] / st['passes']),
-              'launches', st['launches'], ' '.join(f"{nm}={out[k]/P:.0f}" for k, nm in enumerate(names_res if st['launches'] == 1 else names)), 'cycles/pass', flush=True)
+              'launches', st['launches'], ' '.join(f"{nm}={out[k]/P:.0f}" for k, nm in enumerate(names_res if st['launches'] == 1 else names + ["-"])), 'cycles/pass', flush=True)
         if st['launches'] == 1 and n > 100000:  # one epoch's timeline of every workgroup (s_memrealtime, 10 ns ticks)
-            tr = (C.c_longlong * (8 * 256))(); rows = brdf_amd.lib.brdf_hip_last_fit_trace(tr, 256)
-            t = np.array(tr[:], dtype=np.int64).reshape(256, 8)
+            tr = (C.c_longlong * (8 * 257))(); rows = brdf_amd.lib.brdf_hip_last_fit_trace(tr, 257)
+            t = np.array(tr[:], dtype=np.int64).reshape(257, 8)
+            print('    LM step sections (cycles/pass, LM_STAMP 1..7):', ' '.join(f'{v / P:.0f}' for v in t[256, 1:]), flush=True)
+            t = t[:256]
             if t[:, 0].min() > 0:
                 t0 = t[:, 0].min()
                 lead = t[:, 6] > 0

@@ -32,4 +32,4 @@ def test_resident_kernels_do_not_spill_their_samples(tmp_path):
         if m.group(3) == "1":  # FAST (prepared-sample) kernels: the ones every fit with positive cosines takes
             worst[nme] = sp
     assert len(worst) == 15  # 3 models x (dif, bc_dif/bc_der: single fit + batched; der: single fit)
-    assert max(worst.values()) <= 8, worst
+    assert max(worst.values()) <= 12, worst  # (today: 0-8; the batched dlevmar_bc_dif kernel keeps its control wave's samples in registers)
