@@ -28,6 +28,19 @@ using namespace brdf;
 
 namespace {
 
+// levmar documents a FOUR-element opts array for the analytic-Jacobian entry points (lm_core.c:70-75, lmbc_core.c:380):
+// they are widened here so that nothing below ever reads a fifth element of the caller's array
+struct Opts4 {
+  double o[5];
+  double *ptr;
+  explicit Opts4(double *opts) : ptr(opts ? o : nullptr) {
+    if (opts) {
+      for (int i = 0; i < 4; ++i) o[i] = opts[i];
+      o[4] = LM_DIFF_DELTA;
+    }
+  }
+};
+
 typedef void (*model_func_t)(double *, double *, int, int, void *);
 constexpr int kMaxRegistered = 16;
 model_func_t g_registered[kMaxRegistered] = {nullptr};
@@ -39,6 +52,46 @@ bool is_registered(model_func_t f) {
   for (int i = 0; i < kMaxRegistered; ++i)
     if (g_registered[i] == f) return true;
   return false;
+}
+
+// Grow-only device staging of the drop-in entry points (one per host thread): a dlevmar_* call with host pointers
+// uploads its planes and measurements here.  The first version hipMalloc'ed and hipFree'd two buffers per call -- at the
+// application's call site (brdfdata.cpp:1119: n = 16, once per pixel and colour channel) that pair cost more than the fit.
+struct HostStage {
+  double *d = nullptr;
+  size_t cap = 0;
+  int dev = -1;
+  double *get(size_t count) {
+    int cur = 0;
+    if (hipGetDevice(&cur) != hipSuccess) return nullptr;
+    if (d && cur == dev && cap >= count) return d;
+    if (d) {
+      (void)hipDeviceSynchronize();
+      (void)hipFree(d);
+      d = nullptr;
+      cap = 0;
+    }
+    const size_t want = count + count / 2 + 1024;
+    if (hipMalloc(&d, want * sizeof(double)) != hipSuccess) {
+      set_error("hipMalloc(%zu doubles) failed", want);
+      d = nullptr;
+      return nullptr;
+    }
+    cap = want;
+    dev = cur;
+    return d;
+  }
+};
+thread_local HostStage g_stage;
+
+// uploads the planes `modelInfo` reads (Blinn-Phong never reads plane 3, which the reference's per-surfel caller
+// allocates and fills incorrectly, brdfdata.cpp:1095, :1102) into d[0, 3n): adjacent planes travel in one copy
+hipError_t upload_planes(double *d, const double *angles, int n, int model) {
+  if (model == MODEL_WARD) return hipMemcpy(d, angles, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice);
+  if (model == MODEL_BLINN_PHONG) return hipMemcpy(d, angles, sizeof(double) * 2 * (size_t)n, hipMemcpyHostToDevice);
+  hipError_t e = hipMemcpy(d, angles, sizeof(double) * n, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d + 2 * (size_t)n, angles + 2 * (size_t)n, sizeof(double) * n, hipMemcpyHostToDevice);
+  return e;
 }
 
 // scoped device buffer
@@ -88,18 +141,12 @@ int host_fit(int method, const char *who, model_func_t func, double *p, double *
               ed->modelInfo);
     return LM_ERROR;
   }
-  DevBuf angles, xs;
-  if (angles.alloc(3 * (size_t)n) || xs.alloc((size_t)n)) return LM_ERROR;
-  // Blinn-Phong never reads plane 3 and the reference's per-surfel caller allocates/fills it
-  // incorrectly (brdfdata.cpp:1095, :1102): only the planes the model reads are copied.
-  const bool need1 = ed->modelInfo != MODEL_PHONG, need2 = ed->modelInfo != MODEL_BLINN_PHONG;
-  hipError_t e = hipMemcpy(angles.ptr, ed->angles, sizeof(double) * n, hipMemcpyHostToDevice);
-  if (e == hipSuccess && need1)
-    e = hipMemcpy(angles.ptr + n, ed->angles + n, sizeof(double) * n, hipMemcpyHostToDevice);
-  if (e == hipSuccess && need2)
-    e = hipMemcpy(angles.ptr + 2 * (size_t)n, ed->angles + 2 * (size_t)n, sizeof(double) * n, hipMemcpyHostToDevice);
+  double *stage = g_stage.get(4 * (size_t)n);
+  if (!stage) return LM_ERROR;
+  double *d_angles = stage, *d_x = stage + 3 * (size_t)n;
+  hipError_t e = upload_planes(d_angles, ed->angles, n, ed->modelInfo);
   if (e == hipSuccess)  // "NULL implies a zero vector", lm_core.c:441 / misc_core.c:770
-    e = x ? hipMemcpy(xs.ptr, x, sizeof(double) * n, hipMemcpyHostToDevice) : hipMemset(xs.ptr, 0, sizeof(double) * n);
+    e = x ? hipMemcpy(d_x, x, sizeof(double) * n, hipMemcpyHostToDevice) : hipMemset(d_x, 0, sizeof(double) * n);
   if (e != hipSuccess) {
     set_error("%s(): host->device copy failed: %s", who, hipGetErrorString(e));
     return LM_ERROR;
@@ -108,8 +155,8 @@ int host_fit(int method, const char *who, model_func_t func, double *p, double *
   a.method = method;
   a.analytic = analytic;
   a.model = ed->modelInfo;
-  a.d_angles = angles.ptr;
-  a.d_x = xs.ptr;
+  a.d_angles = d_angles;
+  a.d_x = d_x;
   a.n = n;
   a.p = p;
   a.lb = lb;
@@ -120,9 +167,9 @@ int host_fit(int method, const char *who, model_func_t func, double *p, double *
   a.info = info;
   a.covar = covar;
   a.stream = nullptr;
-  const int ret = stream_fit_run(a);
-  (void)hipStreamSynchronize(nullptr);  // run-ahead launches still reference the buffers freed below
-  return ret;
+  // (the fit has finished when this returns: launches of the chain still queued behind it only read its `done` word,
+  // never the staging buffer, so the next call may overwrite the buffer at once)
+  return stream_fit_run(a);
 }
 
 }  // namespace
@@ -154,6 +201,8 @@ int dlevmar_der(void (*func)(double *, double *, int, int, void *), void (*jacf)
               "dlevmar_dif() rather than dlevmar_der()");
     return LM_ERROR;
   }
+  Opts4 o4(opts);
+  opts = o4.ptr;
   if (is_registered(func) && jacf == &BRDFJac_hip) {  // a built-in model with its own analytic Jacobian: resident regime
     double keep[8];
     for (int i = 0; i < m && i < 8; ++i) keep[i] = p[i];
@@ -176,6 +225,8 @@ int dlevmar_bc_der(void (*func)(double *, double *, int, int, void *), void (*ja
               "use dlevmar_bc_dif() rather than dlevmar_bc_der()");
     return LM_ERROR;
   }
+  Opts4 o4(opts);
+  opts = o4.ptr;
   if (is_registered(func) && jacf == &BRDFJac_hip)  // a built-in model with its own analytic Jacobian: all on the device
     return host_fit(BRDF_METHOD_BC_DIF, "dlevmar_bc_der", func, p, x, m, n, lb, ub, dscl, itmax, opts, info, covar, adata,
                     /*analytic=*/1);
@@ -217,19 +268,16 @@ void BRDFFunc_hip(double *p, double *hx, int m, int n, void *adata) {
     return;
   }
   if (ed->modelInfo < 0 || ed->modelInfo >= MODEL_COUNT) return;  // reference: hx left unwritten
-  DevBuf angles, out;
-  if (angles.alloc(3 * (size_t)n) || out.alloc((size_t)n)) return;
-  const bool need1 = ed->modelInfo != MODEL_PHONG, need2 = ed->modelInfo != MODEL_BLINN_PHONG;
-  hipError_t e = hipMemcpy(angles.ptr, ed->angles, sizeof(double) * n, hipMemcpyHostToDevice);
-  if (e == hipSuccess && need1) e = hipMemcpy(angles.ptr + n, ed->angles + n, sizeof(double) * n, hipMemcpyHostToDevice);
-  if (e == hipSuccess && need2)
-    e = hipMemcpy(angles.ptr + 2 * (size_t)n, ed->angles + 2 * (size_t)n, sizeof(double) * n, hipMemcpyHostToDevice);
+  double *stage = g_stage.get(4 * (size_t)n);
+  if (!stage) return;
+  double *d_out = stage + 3 * (size_t)n;
+  hipError_t e = upload_planes(stage, ed->angles, n, ed->modelInfo);
   if (e != hipSuccess) {
     set_error("BRDFFunc_hip(): host->device copy failed: %s", hipGetErrorString(e));
     return;
   }
-  if (model_eval_run(ed->modelInfo, angles.ptr, n, p, out.ptr, nullptr) != 0) return;
-  e = hipMemcpy(hx, out.ptr, sizeof(double) * n, hipMemcpyDeviceToHost);
+  if (model_eval_run(ed->modelInfo, stage, n, p, d_out, nullptr) != 0) return;
+  e = hipMemcpy(hx, d_out, sizeof(double) * n, hipMemcpyDeviceToHost);
   if (e != hipSuccess) set_error("BRDFFunc_hip(): device->host copy failed: %s", hipGetErrorString(e));
 }
 
@@ -240,19 +288,16 @@ void BRDFJac_hip(double *p, double *jac, int m, int n, void *adata) {
     return;
   }
   if (ed->modelInfo < 0 || ed->modelInfo >= MODEL_COUNT) return;
-  DevBuf angles, out;
-  if (angles.alloc(3 * (size_t)n) || out.alloc(3 * (size_t)n)) return;
-  const bool need1 = ed->modelInfo != MODEL_PHONG, need2 = ed->modelInfo != MODEL_BLINN_PHONG;
-  hipError_t e = hipMemcpy(angles.ptr, ed->angles, sizeof(double) * n, hipMemcpyHostToDevice);
-  if (e == hipSuccess && need1) e = hipMemcpy(angles.ptr + n, ed->angles + n, sizeof(double) * n, hipMemcpyHostToDevice);
-  if (e == hipSuccess && need2)
-    e = hipMemcpy(angles.ptr + 2 * (size_t)n, ed->angles + 2 * (size_t)n, sizeof(double) * n, hipMemcpyHostToDevice);
+  double *stage = g_stage.get(6 * (size_t)n);
+  if (!stage) return;
+  double *d_out = stage + 3 * (size_t)n;
+  hipError_t e = upload_planes(stage, ed->angles, n, ed->modelInfo);
   if (e != hipSuccess) {
     set_error("BRDFJac_hip(): host->device copy failed: %s", hipGetErrorString(e));
     return;
   }
-  if (model_jac_run(ed->modelInfo, angles.ptr, n, p, out.ptr, nullptr) != 0) return;
-  e = hipMemcpy(jac, out.ptr, sizeof(double) * 3 * n, hipMemcpyDeviceToHost);
+  if (model_jac_run(ed->modelInfo, stage, n, p, d_out, nullptr) != 0) return;
+  e = hipMemcpy(jac, d_out, sizeof(double) * 3 * n, hipMemcpyDeviceToHost);
   if (e != hipSuccess) set_error("BRDFJac_hip(): device->host copy failed: %s", hipGetErrorString(e));
 }
 

@@ -824,6 +824,10 @@ struct RWorkspace {
   long long h_trace[8 * (kRowStride + 1)] = {0};  // + one row: the sections of the LM step (LM_STAMP)
   unsigned tag_base = 0;
   FitStats stats{};
+  // After a launch that could not run co-resident (GPU shared with other kernels / ranks: every workgroup burns its
+  // spin budget before the launch drains) the resident path steps aside for the next `skip` fits, doubling up to
+  // 1024 while it keeps failing, instead of paying that budget on every fit.
+  int backoff = 0, skip = 0;
 
   int ensure(int dev) {
     if (device == dev && d_block) return 0;
@@ -914,6 +918,15 @@ int resident_attempt(const StreamFitArgs &a, RWorkspace &ws, bool *retry_exact, 
   if (const char *e = getenv("BRDF_HIP_RESIDENT_SPIN_MS")) c.spin_ticks = std::max(1LL, atoll(e)) * 100000LL;
   if (const char *e = getenv("BRDF_HIP_RESIDENT_SABOTAGE")) c.sabotage_epoch = atoi(e);  // tests only: forces the fallback
 
+  {  // one workgroup per CU must be able to live there at all (registers, LDS): checked once per kernel
+    static int per_cu = -1;
+    if (per_cu < 0 && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, resident_fit_kernel<MODEL, METHOD, FAST, false>, kRThreads, 0) != hipSuccess)
+      per_cu = 0;
+    if (per_cu < 1) {
+      *unavailable = true;
+      return 0;
+    }
+  }
   hipLaunchKernelGGL((resident_fit_kernel<MODEL, METHOD, FAST, false>), dim3(G), dim3(kRThreads), 0, a.stream, c, BatchCtx{});
   HIP_OK(hipGetLastError());
   {  // wait on the pinned mailbox (a stream synchronise sleeps and wakes up tens of microseconds late); the launch
@@ -1028,6 +1041,10 @@ bool resident_fit_try(const StreamFitArgs &a, int *ret) {
   RWorkspace &ws = g_rws;
   if (ws.ensure(dev) != 0) return false;
   if ((long long)a.n > (long long)ws.cus * kRTile || ws.cus > kRowStride) return false;  // does not fit the chip: launch chain
+  if (ws.skip > 0) {  // stepping aside after an aborted launch
+    --ws.skip;
+    return false;
+  }
   bool unavailable = false;
   int r;
   switch (a.model * 3 + a.method) {
@@ -1047,8 +1064,12 @@ bool resident_fit_try(const StreamFitArgs &a, int *ret) {
     static bool warned = false;
     if (!warned) fprintf(stderr, "libbrdf_hip: resident single-launch path unavailable (grid not co-resident?); using the launch chain\n");
     warned = true;
+    ws.backoff = std::min(1024, std::max(8, ws.backoff * 2));
+    ws.skip = ws.backoff;
+    if (const char *e = getenv("BRDF_HIP_RESIDENT_BACKOFF")) ws.skip = std::max(0, atoi(e));  // tests
     return false;
   }
+  ws.backoff = 0;
   *ret = r;
   return true;
 }

@@ -3,7 +3,7 @@ xGMI on ROCm; "gloo" on CPU for tests).
 
 Fits are independent (brdfdata.cpp:1195-1220 carries nothing between iterations of the pixel loop), so the
 data path has NO collective: rank r generates/loads and fits only its own contiguous surfel range.  The one
-collective of a job is the final gather of the fitted parameters + info[] to rank 0 (S x 13 doubles in total:
+collective of a job is the final gather of the fitted parameters + info[] to rank 0 (S x 14 doubles in total:
 65,536 surfels -> 6.8 MB, i.e. < 1 MB per peer over seven point-to-point xGMI links; a ring would be per-link
 bound and is unnecessary).
 """

@@ -65,7 +65,8 @@ def fit_batch(method: int, model: int, angles, x, p0, *, lb=None, ub=None, itmax
     Returns (p [S,3], info [S,10], ret [S] int32) as CUDA tensors; asynchronous on the current stream.
     """
     import torch
-    assert angles.is_cuda and x.is_cuda and p0.is_cuda
+    assert angles.is_cuda and x.is_cuda and p0.is_cuda and angles.device == x.device == p0.device
+    assert angles.dtype == torch.float64 and x.dtype == torch.float64 and p0.dtype == torch.float64  # the kernels read raw doubles
     S, n = x.shape
     assert tuple(angles.shape) == (S, 3, n) and tuple(p0.shape) == (S, 3)
     angles = angles.contiguous()
@@ -86,6 +87,7 @@ def fit_batch(method: int, model: int, angles, x, p0, *, lb=None, ub=None, itmax
 def model_eval(model: int, angles, p):
     """hx = model(p; samples) on the device (kernel K1 alone).  angles: CUDA float64 [3,n]."""
     import torch
+    assert angles.is_cuda and angles.dtype == torch.float64 and angles.numel() % 3 == 0
     angles = angles.contiguous()
     n = angles.numel() // 3
     hx = torch.empty(n, dtype=torch.float64, device=angles.device)
@@ -111,10 +113,14 @@ def cosines(vertices, faces, face_normals, leds, view_origin, *, surfels=None, r
     [S, 3, L] -- the batched fitter's `angles` layout."""
     import torch
     vertices, faces, face_normals = vertices.contiguous(), faces.contiguous(), face_normals.contiguous()
+    assert vertices.is_cuda and faces.is_cuda and face_normals.is_cuda
     assert vertices.dtype == torch.float64 and face_normals.dtype == torch.float64 and faces.dtype == torch.int32
+    assert vertices.shape[-1] == 3 and faces.shape[-1] == 3 and tuple(face_normals.shape) == (faces.shape[0], 3)
+    assert faces.numel() == 0 or (int(faces.min()) >= 0 and int(faces.max()) < vertices.shape[0]), "face index outside the vertex array"
     if surfels is not None:
         surfels = surfels.contiguous()
-        assert surfels.dtype == torch.int32
+        assert surfels.is_cuda and surfels.dtype == torch.int32
+        assert surfels.numel() == 0 or (int(surfels.min()) >= 0 and int(surfels.max()) < faces.shape[0]), "surfel index outside the face array"
     S = int(surfels.numel()) if surfels is not None else int(faces.shape[0])
     la = np.ascontiguousarray(leds, dtype=np.float64).reshape(-1, 3)
     L = la.shape[0]
@@ -137,7 +143,12 @@ def fit_capture(model: int, images, pixel_map, vertices, faces, face_normals, le
     import torch
     images, pixel_map = images.contiguous(), pixel_map.contiguous()
     vertices, faces, face_normals = vertices.contiguous(), faces.contiguous(), face_normals.contiguous()
+    assert images.is_cuda and pixel_map.is_cuda and vertices.is_cuda and faces.is_cuda and face_normals.is_cuda
     assert images.dtype == torch.uint8 and pixel_map.dtype == torch.int32 and faces.dtype == torch.int32
+    assert vertices.dtype == torch.float64 and face_normals.dtype == torch.float64
+    assert images.dim() == 4 and images.shape[3] == 3 and tuple(pixel_map.shape) == tuple(images.shape[1:3])  # [L,H,W,3] BGR, [H,W]
+    assert tuple(face_normals.shape) == (faces.shape[0], 3) and vertices.shape[-1] == 3
+    assert int(pixel_map.max()) < faces.shape[0], "pixel map names a face that does not exist"
     L, H, W = int(images.shape[0]), int(images.shape[1]), int(images.shape[2])
     nf = int(faces.shape[0])
     if brdf_surfaces is None:
@@ -167,7 +178,12 @@ def fit_capture_single(model: int, images, pixel_map, vertices, faces, face_norm
     import torch
     images, pixel_map = images.contiguous(), pixel_map.contiguous()
     vertices, faces, face_normals = vertices.contiguous(), faces.contiguous(), face_normals.contiguous()
+    assert images.is_cuda and pixel_map.is_cuda and vertices.is_cuda and faces.is_cuda and face_normals.is_cuda
     assert images.dtype == torch.uint8 and pixel_map.dtype == torch.int32 and faces.dtype == torch.int32
+    assert vertices.dtype == torch.float64 and face_normals.dtype == torch.float64
+    assert images.dim() == 4 and images.shape[3] == 3 and tuple(pixel_map.shape) == tuple(images.shape[1:3])  # [L,H,W,3] BGR, [H,W]
+    assert tuple(face_normals.shape) == (faces.shape[0], 3) and vertices.shape[-1] == 3
+    assert int(pixel_map.max()) < faces.shape[0], "pixel map names a face that does not exist"
     L, H, W = int(images.shape[0]), int(images.shape[1]), int(images.shape[2])
     nf = int(faces.shape[0])
     la = np.ascontiguousarray(leds, dtype=np.float64).reshape(-1, 3)

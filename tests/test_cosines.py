@@ -202,14 +202,19 @@ def test_device_capture_loop_against_oracle(gpu):
     # 16-sample fits are ill-conditioned (SURVEY.md section 6 ii): parity on the objective of the pixel that owns the face
     ang = L.cosines(vertices, faces, nrm, leds, view, rv_mode=1)
     H, W = pixel_map.shape
-    worst = 0.0
+    errs = []
     for f in touched:
         x_, y_ = max((x, y) for y in range(H) for x in range(W) if pixel_map[y, x] == f)
         for ch in range(3):
             I = images[:, H - 1 - y_, x_, ch] / 255.0
             o_got, o_ref = _objective(1, ang[f], I, got[f, ch]), _objective(1, ang[f], I, want[f, ch])
             assert o_got <= o_ref * (1 + 1e-3) + 1e-12, (f, ch, got[f, ch], want[f, ch])
-            worst = max(worst, L.rel_err(got[f, ch], want[f, ch]))
+            errs.append(L.rel_err(got[f, ch], want[f, ch]))
+    # the {kd, ks, n} written to brdf_surfaces themselves: the lane-per-fit kernel sums in the reference's order, so the fits
+    # differ from the CPU walk only where a last-bit difference of exp/pow sends an ill-conditioned fit down another path
+    errs = np.array(errs)
+    print(f"capture: {np.mean(errs <= 1e-5):.3f} of {errs.size} (face, channel) fits within 1e-5 of the CPU walk, worst {errs.max():.2e}")
+    assert np.mean(errs <= 1e-5) >= 0.9
     assert np.all(np.isfinite(avg)) and np.all(np.abs(avg - avg_ref) <= 0.05 * np.abs(avg_ref) + 1e-6)
 
 

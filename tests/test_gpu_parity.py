@@ -274,6 +274,44 @@ def test_both_kernels_for_sixteen_sample_fits(gpu, monkeypatch, rows):
                 assert info[s, 1] <= info_ref[1] * (1 + 1e-3) + 1e-30
 
 
+@pytest.mark.parametrize("exact_pow", ["0", "1"])
+@pytest.mark.parametrize("model", [1, 0])
+def test_sixteen_sample_fits_fit_by_fit_against_the_oracle(gpu, monkeypatch, model, exact_pow):
+    """The application's own workload (brdfdata.cpp:1119: 16 lights, dlevmar_bc_dif, once per pixel and channel) on
+    8-bit-quantised noisy measurements (GetIntensities_FromPixel, brdfdata.cpp:945-960: value / 255), through the
+    lane-per-fit kernel that is the default at this size -- on the default path (exp(n log c)) and with
+    BRDF_HIP_EXACT_POW=1 (the reference's pow expression).  The kernel sums in the reference's own order, so what is
+    left between it and the CPU reference is the last bit of pow / exp (ocml vs glibc); these fits are ill-conditioned
+    (SURVEY.md section 6 ii: 14 % end at itmax), so a last-bit difference CAN send a fit down another path.  What is
+    asserted, fit by fit: both succeed or both fail; >= 97 % of the fits that converge on both sides agree to 1e-5 on
+    {kd, ks, n}; no fit ends with an objective more than 30 % above the reference's; >= 99 % are within 1e-6 of it or
+    better."""
+    monkeypatch.setenv("BRDF_HIP_EXACT_POW", exact_pow)
+    n, S = 16, 768
+    angles, x, _ = synth.make_surfels(model, n, first=4000, count=S)
+    x = np.round(np.clip(x, 0.0, 1.0) * 255.0) / 255.0  # the capture's 8-bit measurements
+    p0 = np.tile(np.array(synth.P0[model]), (S, 1))
+    p, info, ret = _batch(gpu, 1, model, angles, x, p0)
+    both = close = near = same = 0
+    worst = 0.0
+    for s in range(S):
+        r, p_ref, info_ref = L.brdf_fit("orc", 1, model, angles[s], x[s], synth.P0[model], synth.ITMAX, synth.OPTS, synth.LB, synth.UB)
+        assert (ret[s] >= 0) == (r >= 0), (s, ret[s], r)
+        if r < 0:
+            continue
+        excess = (info[s, 1] - info_ref[1]) / max(info_ref[1], 1e-300)
+        worst = max(worst, excess)
+        near += int(excess <= 1e-6)
+        same += int(np.array_equal(info[s, 5:8], info_ref[5:8]))
+        if info_ref[6] != 3 and info[s, 6] != 3:
+            both += 1
+            close += int(L.rel_err(p[s], p_ref) <= P_TOL)
+    print(f"n=16 model {model} exact_pow={exact_pow}: {close}/{both} converged fits within 1e-5, {near}/{S} objectives within 1e-6, "
+          f"{same}/{S} identical (iterations, reason, nfev), worst objective excess {worst:.3e}")
+    assert both >= 0.7 * S and close >= 0.97 * both, (close, both)
+    assert near >= 0.99 * S and worst <= 0.3, (near, worst)
+
+
 def test_batch_results_do_not_depend_on_batch_composition(gpu):
     """fits are independent: fitting surfels [0,64) at once or in two halves gives bit-identical outputs
     (this is what makes sharding across GPUs exact)"""
@@ -344,6 +382,7 @@ def test_resident_regime_falls_back_when_a_workgroup_never_arrives(gpu, monkeypa
     monkeypatch.setenv("BRDF_HIP_RESIDENT", "1")
     monkeypatch.setenv("BRDF_HIP_RESIDENT_SABOTAGE", "3")
     monkeypatch.setenv("BRDF_HIP_RESIDENT_SPIN_MS", "20")
+    monkeypatch.setenv("BRDF_HIP_RESIDENT_BACKOFF", "0")  # (no stepping aside after an abort: every fit below tries the resident launch)
     model, n = 2, 100000
     angles, x, _ = synth.make_single(model, n)
     for method in (0, 1):
@@ -354,6 +393,15 @@ def test_resident_regime_falls_back_when_a_workgroup_never_arrives(gpu, monkeypa
     _check(_dev_fit(gpu, 0, model, angles, x), *L.brdf_fit("orc", 0, model, angles, x, synth.P0[model], synth.ITMAX, synth.OPTS,
                                                           synth.LB, synth.UB)[1:])
     assert brdf_amd.last_fit_stats()["launches"] == 1  # and the resident regime works again afterwards (tags restarted)
+    # after an aborted launch the resident path steps aside for the next fits (default 8, doubling; here 2) instead of
+    # burning its spin budget on every call of a process that shares the GPU
+    monkeypatch.setenv("BRDF_HIP_RESIDENT_SABOTAGE", "3")
+    monkeypatch.setenv("BRDF_HIP_RESIDENT_BACKOFF", "2")
+    assert _dev_fit(gpu, 0, model, angles, x).ret >= 0 and brdf_amd.last_fit_stats()["launches"] > 1  # aborted, chain
+    monkeypatch.delenv("BRDF_HIP_RESIDENT_SABOTAGE")
+    for expect_chain in (True, True, False):
+        assert _dev_fit(gpu, 0, model, angles, x).ret >= 0
+        assert (brdf_amd.last_fit_stats()["launches"] > 1) == expect_chain
 
 
 @pytest.mark.parametrize("model", [0, 1, 2])
