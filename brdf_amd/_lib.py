@@ -30,6 +30,8 @@ ABI = {
     "dlevmar_bc_der": (C.c_int, [C.c_void_p, C.c_void_p, D, D, C.c_int, C.c_int, D, D, D, C.c_int, D, D, D, D, C.c_void_p]),
     "dlevmar_stddev": (C.c_double, [D, C.c_int, C.c_int]),
     "dlevmar_corcoef": (C.c_double, [D, C.c_int, C.c_int, C.c_int]),
+    "dlevmar_R2": (C.c_double, [C.c_void_p, D, D, C.c_int, C.c_int, C.c_void_p]),
+    "dAx_eq_b_LU_noLapack": (C.c_int, [D, D, D, C.c_int]),
     "brdf_hip_register_model": (C.c_int, [C.c_void_p]),
     "brdf_hip_unregister_model": (C.c_int, [C.c_void_p]),
     "BRDFFunc_hip": (None, [D, D, C.c_int, C.c_int, C.c_void_p]),

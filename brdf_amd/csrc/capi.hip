@@ -4,7 +4,9 @@
 // levmar.h:112-127 signatures and semantics (return value, info[], NULL-able opts/info/work/covar,
 // stderr diagnostics, LM_ERROR instead of exit()).  Everything n-sized runs in the HIP kernels of
 // stream_fit.hip / batch_fit.hip; there is no CPU evaluation path in this library.
+#include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <mutex>
 
@@ -22,6 +24,7 @@ int generic_fit_run(int method, void (*func)(double *, double *, int, int, void 
 int model_eval_run(int model, const double *d_angles, int n, const double *p, double *d_hx, hipStream_t stream);
 int model_jac_run(int model, const double *d_angles, int n, const double *p, double *d_jac, hipStream_t stream);
 int chkjac_err_run(const double *fvec, const double *fjac, const double *fvecp, const double *p, int m, int n, double *err);
+int r2_run(const double *x, const double *hx, int n, double *r2);
 }
 
 using namespace brdf;
@@ -236,6 +239,91 @@ int dlevmar_bc_der(void (*func)(double *, double *, int, int, void *), void (*ja
 /* scalar post-processing of the covariance the solvers return (misc_core.c:598-611); no n-sized work */
 double dlevmar_stddev(double *covar, int m, int i) { return sqrt(covar[i * m + i]); }
 double dlevmar_corcoef(double *covar, int m, int i, int j) { return covar[i * m + j] / sqrt(covar[i * m + i] * covar[j * m + j]); }
+
+double dlevmar_R2(void (*func)(double *, double *, int, int, void *), double *p, double *x, int m, int n, void *adata) {
+  if (!func || !p || m <= 0 || n <= 0) {
+    set_error("dlevmar_R2(): bad arguments");
+    return NAN;
+  }
+  std::vector<double> hx(n);
+  (*func)(p, hx.data(), m, n, adata);  // misc_core.c:632
+  double r2 = NAN;
+  (void)r2_run(x, hx.data(), n, &r2);
+  return r2;
+}
+
+/* Axb_core.c:1197-1270 for a run-time m: Crout LU with implicit row scaling + partial pivoting, zero pivot -> DBL_EPSILON,
+ * forward and back substitution.  Same operations in the same order as lm_machine.h: lu_solve<M> (which the fitter uses in
+ * registers and which the reference's known answers pin bit for bit). */
+int dAx_eq_b_LU_noLapack(double *A, double *B, double *x, int m) {
+  if (!A) return 1;  // Axb_core.c:1149-1157: "release the retained buffer" -- there is none here
+  if (!B || !x || m <= 0) {
+    set_error("dAx_eq_b_LU_noLapack(): bad arguments");
+    return 0;
+  }
+  std::vector<double> a(A, A + (size_t)m * m), scale(m);
+  std::vector<int> perm(m);
+  for (int i = 0; i < m; ++i) x[i] = B[i];
+  for (int i = 0; i < m; ++i) {
+    double big = 0.0;
+    for (int j = 0; j < m; ++j) {
+      const double t = fabs(a[(size_t)i * m + j]);
+      if (t > big) big = t;
+    }
+    if (big == 0.0) {
+      fprintf(stderr, "Singular matrix A in dAx_eq_b_LU_noLapack()!\n");  // Axb_core.c:1203-1206
+      return 0;
+    }
+    scale[i] = 1.0 / big;
+  }
+  for (int j = 0; j < m; ++j) {
+    int pivot = j;
+    double big = 0.0;
+    for (int i = 0; i < j; ++i) {
+      double s = a[(size_t)i * m + j];
+      for (int k = 0; k < i; ++k) s -= a[(size_t)i * m + k] * a[(size_t)k * m + j];
+      a[(size_t)i * m + j] = s;
+    }
+    for (int i = j; i < m; ++i) {
+      double s = a[(size_t)i * m + j];
+      for (int k = 0; k < j; ++k) s -= a[(size_t)i * m + k] * a[(size_t)k * m + j];
+      a[(size_t)i * m + j] = s;
+      const double t = scale[i] * fabs(s);
+      if (t >= big) {
+        big = t;
+        pivot = i;
+      }
+    }
+    if (j != pivot) {
+      for (int k = 0; k < m; ++k) std::swap(a[(size_t)pivot * m + k], a[(size_t)j * m + k]);
+      scale[pivot] = scale[j];
+    }
+    perm[j] = pivot;
+    if (a[(size_t)j * m + j] == 0.0) a[(size_t)j * m + j] = DBL_EPSILON;
+    if (j != m - 1) {
+      const double t = 1.0 / a[(size_t)j * m + j];
+      for (int i = j + 1; i < m; ++i) a[(size_t)i * m + j] *= t;
+    }
+  }
+  int first = 0;
+  for (int i = 0; i < m; ++i) {
+    const int ip = perm[i];
+    double s = x[ip];
+    x[ip] = x[i];
+    if (first != 0) {
+      for (int jj = first - 1; jj < i; ++jj) s -= a[(size_t)i * m + jj] * x[jj];
+    } else if (s != 0.0) {
+      first = i + 1;
+    }
+    x[i] = s;
+  }
+  for (int i = m - 1; i >= 0; --i) {
+    double s = x[i];
+    for (int j = i + 1; j < m; ++j) s -= a[(size_t)i * m + j] * x[j];
+    x[i] = s / a[(size_t)i * m + i];
+  }
+  return 1;
+}
 
 int brdf_hip_register_model(void (*func)(double *, double *, int, int, void *)) {
   if (!func) return -1;

@@ -480,4 +480,75 @@ int chkjac_err_run(const double *fvec, const double *fjac, const double *fvecp, 
   return 0;
 }
 
+
+// dlevmar_R2's three sums (misc_core.c:634-654): sum x, then SS_err and SS_tot, each walked from the top index down.
+// Small problems: one lane, the reference's order.  Large ones: per-lane strided partial sums folded by a fixed tree.
+__global__ __launch_bounds__(256) void r2_kernel(const double *__restrict__ x, const double *__restrict__ hx, int n, int exact,
+                                                 double *__restrict__ out) {
+  __shared__ double part[3][256];
+  const int tid = threadIdx.x;
+  if (exact) {
+    if (tid == 0) {
+      double sx = 0.0;
+      for (int i = n; i-- > 0;) sx += x[i];
+      const double xavg = sx / (double)n;
+      double sse = 0.0, sst = 0.0;
+      for (int i = n; i-- > 0;) {
+        double t = x[i] - hx[i];
+        sse += t * t;
+        t = x[i] - xavg;
+        sst += t * t;
+      }
+      out[0] = 1.0 - sse / sst;
+    }
+    return;
+  }
+  auto fold = [&](int k) {
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (tid < s) part[k][tid] += part[k][tid + s];
+      __syncthreads();
+    }
+  };
+  double sx = 0.0;
+  for (int i = tid; i < n; i += 256) sx += x[i];
+  part[0][tid] = sx;
+  fold(0);
+  const double xavg = part[0][0] / (double)n;
+  double sse = 0.0, sst = 0.0;
+  for (int i = tid; i < n; i += 256) {
+    double t = x[i] - hx[i];
+    sse += t * t;
+    t = x[i] - xavg;
+    sst += t * t;
+  }
+  part[1][tid] = sse;
+  part[2][tid] = sst;
+  fold(1);
+  fold(2);
+  if (tid == 0) out[0] = 1.0 - part[1][0] / part[2][0];
+}
+
+int r2_run(const double *x, const double *hx, int n, double *r2) {
+  (void)hipGetLastError();
+  double *d = nullptr;
+  if (hipMalloc(&d, (2 * (size_t)n + 1) * sizeof(double)) != hipSuccess) {
+    set_error("dlevmar_R2(): hipMalloc failed");
+    return kLmError;
+  }
+  hipError_t e = x ? hipMemcpy(d, x, sizeof(double) * n, hipMemcpyHostToDevice) : hipMemset(d, 0, sizeof(double) * n);
+  if (e == hipSuccess) e = hipMemcpy(d + n, hx, sizeof(double) * n, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(r2_kernel, dim3(1), dim3(256), 0, nullptr, d, d + n, n, n <= kGenExactLimit ? 1 : 0, d + 2 * (size_t)n);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(r2, d + 2 * (size_t)n, sizeof(double), hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess) {
+    set_error("dlevmar_R2(): %s", hipGetErrorString(e));
+    return kLmError;
+  }
+  return 0;
+}
+
 }  // namespace brdf

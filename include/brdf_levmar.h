@@ -22,6 +22,9 @@ extern "C" {
 /* ---- constants, same values as levmar/levmar.h:68-100 -------------------------------------------- */
 #define LM_DIF_WORKSZ(npar, nmeas) (4 * (nmeas) + 4 * (npar) + (nmeas) * (npar) + (npar) * (npar))
 #define LM_BC_DIF_WORKSZ(npar, nmeas) (2 * (nmeas) + 4 * (npar) + (nmeas) * (npar) + (npar) * (npar))
+#define LM_DER_WORKSZ(npar, nmeas) (2 * (nmeas) + 4 * (npar) + (nmeas) * (npar) + (npar) * (npar))    /* levmar.h:68 */
+#define LM_BC_DER_WORKSZ(npar, nmeas) (2 * (nmeas) + 4 * (npar) + (nmeas) * (npar) + (npar) * (npar)) /* levmar.h:74 */
+#define LM_VERSION "2.6 (November 2011)" /* levmar.h:101: the interface version this library stands in for */
 #define LM_OPTS_SZ 5
 #define LM_INFO_SZ 10
 #define LM_ERROR (-1)
@@ -80,6 +83,18 @@ int dlevmar_bc_der(void (*func)(double *p, double *hx, int m, int n, void *adata
  * parameters from the m x m covariance returned through `covar`. */
 double dlevmar_stddev(double *covar, int m, int i);
 double dlevmar_corcoef(double *covar, int m, int i, int j);
+
+/* levmar/levmar.h:376 (misc_core.c:616-658): coefficient of determination R^2 = 1 - SS_err / SS_tot of the model at p.
+ * func is the caller's host callback (evaluated once, on the host); the three n-sized sums run on the device, in the
+ * reference's descending order for n <= 65536.  x == NULL is read as a zero vector (the reference dereferences it). */
+double dlevmar_R2(void (*func)(double *p, double *hx, int m, int n, void *adata), double *p, double *x, int m, int n,
+                  void *adata);
+
+/* levmar/levmar.h:336 (Axb_core.c:1140-1277): solves the m x m system A x = B by Crout LU with implicit row scaling and
+ * partial pivoting; returns 1, or 0 if a row of A is zero.  A == NULL (the reference's "release the retained buffer"
+ * call) does nothing and returns 1.  A scalar O(m^3) utility on the host for callers that link it (lmdemo-style
+ * programs); the fitter itself solves its 3 x 3 systems in device registers.  Re-entrant, unlike the reference's. */
+int dAx_eq_b_LU_noLapack(double *A, double *B, double *x, int m);
 
 /* Declares that `func` has the semantics of the reference's BRDFFunc (brdfdata.cpp:969-989): adata
  * points to a struct laid out like brdf_extra_data and the value depends on modelInfo.  A host

@@ -17,6 +17,9 @@
 
 #define CV_PI 3.1415926535897932384626433832795
 
+// ---- EXCERPT of the reference, kept verbatim ON PURPOSE (brdfdata.cpp:962-989: struct extraData and BRDFFunc; only the
+// call counter is added): the point of this test is that the application's own callback and payload type compile
+// and link UNCHANGED against include/brdf_levmar.h + libbrdf_hip.so.  Everything below the excerpt is this test's own.
 struct extraData {
   double *angles;
   int modelInfo;
@@ -42,38 +45,31 @@ void BRDFFunc(double *p, double x[], int m, int n, void *data) {
   }
   (void)m;
 }
+// ---- end of the excerpt ----------------------------------------------------------------------------------------------
 
 int main(int argc, char **argv) {
   if (argc < 4) return 2;
   const int model = atoi(argv[1]), n = atoi(argv[2]);
-  std::vector<double> buf(4 * (size_t)n);
+  std::vector<double> samples(4 * (size_t)n);  // planes [3][n], then the n measurements
   FILE *f = fopen(argv[3], "rb");
-  if (!f || fread(buf.data(), sizeof(double), buf.size(), f) != buf.size()) return 3;
+  if (!f || fread(samples.data(), sizeof(double), samples.size(), f) != samples.size()) return 3;
   fclose(f);
 
   brdf_hip_register_model(BRDFFunc);  // <- the one added line
 
-  double p[3] = {0.5, 1.0, 1.0};
-  double *x = buf.data() + 3 * (size_t)n;
-  extraData *data = new extraData();
-  data->angles = buf.data();
-  data->modelInfo = model;
-
-  int m = 3;  // parameters
-  int itmax = 100;
-  double opts[LM_OPTS_SZ];
-  double info[LM_INFO_SZ];
-  double lower[] = {0, 0, 0};
-  double upper[] = {100, 100, 100};
-  opts[0] = LM_INIT_MU; opts[1] = 1E-15; opts[2] = 1E-15; opts[3] = 1E-20;
-  opts[4] = LM_DIFF_DELTA;
-
-  int error = dlevmar_bc_dif(BRDFFunc, p, x, m, n, lower, upper, NULL, itmax, opts, info, NULL, NULL, data);
-  if (error == -1) printf("Error in SolveEquation(..)\n");
-  printf("RESULT %d %ld", error, g_calls);
-  for (int i = 0; i < 3; ++i) printf(" %a", p[i]);
-  for (int i = 0; i < LM_INFO_SZ; ++i) printf(" %a", info[i]);
+  // the call-site configuration of CBRDFdata::SolveEquation (brdfdata.cpp:1085, :1107-1119): start {0.5, 1, 1}, 100
+  // iterations, box [0, 100]^3, opts {tau = LM_INIT_MU, 1e-15, 1e-15, 1e-20, LM_DIFF_DELTA}, no work / covar buffers
+  extraData payload{samples.data(), model};
+  double fit[3] = {0.5, 1.0, 1.0};
+  double box_lo[3] = {0.0, 0.0, 0.0}, box_hi[3] = {100.0, 100.0, 100.0};
+  double options[LM_OPTS_SZ] = {LM_INIT_MU, 1E-15, 1E-15, 1E-20, LM_DIFF_DELTA};
+  double report[LM_INFO_SZ];
+  const int status = dlevmar_bc_dif(BRDFFunc, fit, samples.data() + 3 * (size_t)n, 3, n, box_lo, box_hi, NULL, 100, options, report,
+                                    NULL, NULL, &payload);
+  if (status == LM_ERROR) printf("Error in SolveEquation(..)\n");
+  printf("RESULT %d %ld", status, g_calls);
+  for (double v : fit) printf(" %a", v);
+  for (double v : report) printf(" %a", v);
   printf("\n");
-  delete data;
   return 0;
 }

@@ -97,3 +97,58 @@ def test_integration_guide_only_names_declared_entry_points():
     assert len(names) >= 10
     missing = sorted(n for n in names if not re.search(r"\b" + re.escape(n) + r"\s*\(", header))
     assert not missing, missing
+
+
+def test_lu_solver_matches_the_restated_reference_bit_for_bit():
+    """dAx_eq_b_LU_noLapack (levmar.h:336, Axb_core.c:1140-1277) is a host-side scalar utility of the drop-in library:
+    same Crout LU as the oracle's restatement (which the lmdemo known answers pin), for run-time m."""
+    import ctypes as C
+    import numpy as np
+    from brdf_amd._lib import D, lib
+    from tests import oracle_libs as L
+    rng = np.random.default_rng(5)
+    for m in (1, 2, 3, 5, 8, 12):
+        for trial in range(20):
+            A = rng.normal(size=(m, m))
+            if trial == 3 and m > 1:
+                A[0, 0] = 0.0  # forces a row exchange
+            if trial == 4 and m > 2:
+                A[:, 1] = A[:, 0]  # singular: the zero pivot becomes DBL_EPSILON, as in the reference
+            B = rng.normal(size=m)
+            x, x_ref = np.zeros(m), np.zeros(m)
+            Ac, Bc = A.copy().reshape(-1), B.copy()
+            r = lib.dAx_eq_b_LU_noLapack(Ac.ctypes.data_as(D), Bc.ctypes.data_as(D), x.ctypes.data_as(D), m)
+            r_ref = L.orc.orc_lu_solve(L.ptr(A.copy().reshape(-1)), L.ptr(B.copy()), L.ptr(x_ref), m)
+            assert r == r_ref == 1 and np.array_equal(x, x_ref, equal_nan=True)
+            assert np.array_equal(Ac.reshape(m, m), A) and np.array_equal(Bc, B)  # inputs untouched
+    Z = np.zeros(9)
+    assert lib.dAx_eq_b_LU_noLapack(Z.ctypes.data_as(D), np.ones(3).ctypes.data_as(D), np.zeros(3).ctypes.data_as(D), 3) == 0  # zero row
+    assert lib.dAx_eq_b_LU_noLapack(None, None, None, 0) == 1  # the reference's "free the retained buffer" call
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` outside a launcher starts two ranks itself (before anything touches a GPU) and relays
+    rank 0's line.  Here over gloo with the fit stubbed (BRDF_BENCH_STUB: plumbing only, no GPU in this container): the
+    gathered output of two ranks must equal the one-rank output (surfels sharded contiguously, one gather per step)."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, BRDF_BENCH_BACKEND="gloo", BRDF_BENCH_STUB="1")
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    lines = {}
+    for gpus in (1, 2):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--workload", "c5", "--surfels", "37",
+                              "--samples", "16", "--steps", "2", "--warmup", "1", "--no-cpu"], capture_output=True, text=True, env=env,
+                             cwd=ROOT, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        js = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(js) == 1, out.stdout  # exactly one JSON line, from rank 0
+        lines[gpus] = json.loads(js[0])
+    assert lines[1]["n_gpus"] == 1 and lines[2]["n_gpus"] == 2
+    assert lines[2]["config"]["surfels"] == 37 and lines[2]["steps"] == 2
+    assert lines[1]["stub_checksum"] == lines[2]["stub_checksum"]  # ragged shards (19 + 18), gathered in surfel order
+    # under a launcher with the wrong world size the bench refuses instead of printing n_gpus: 1
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--workload", "c5", "--no-cpu"], capture_output=True,
+                         text=True, env=dict(env, RANK="0", WORLD_SIZE="1"), cwd=ROOT, timeout=600)
+    assert bad.returncode != 0 and "WORLD_SIZE" in (bad.stderr + bad.stdout)
