@@ -109,7 +109,7 @@ def cpu_baseline_batched(method, model, n, total, budget_s=10.0):
     """SURVEY.md section 8d / BASELINE.md section 3: the reference's CPU levmar on ALL host cores, one worker process
     per core, worker w fitting surfels w, w + cores, ... of the same workload for `budget_s` seconds each (a bounded
     sample of the S surfels).  Rate = fitted residual-evals / the slowest worker's busy time."""
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
     # the helper module synth.py is imported by file path so that the workers never load the HIP library or torch
     code = ("import sys, importlib.util, types; sys.path.insert(0, %r); "
             "pkg = types.ModuleType('brdf_amd'); pkg.__path__ = [%r]; sys.modules['brdf_amd'] = pkg; "
@@ -128,6 +128,27 @@ def cpu_baseline_batched(method, model, n, total, budget_s=10.0):
 # ---------------------------------------------------------------------------------------------------------------------
 # helpers
 # ---------------------------------------------------------------------------------------------------------------------
+def host_cores():
+    """worker processes of the all-core CPU baseline = the host cores this job may really use: the scheduler affinity, cut
+    down by a cgroup CPU quota if there is one, by BRDF_BENCH_CPU_WORKERS if set, and by 16 per visible GPU (the CPU
+    share that comes with one GPU of a shared node)"""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = min(cores, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    if os.environ.get("BRDF_BENCH_CPU_WORKERS"):
+        return max(1, min(cores, int(os.environ["BRDF_BENCH_CPU_WORKERS"])))
+    try:
+        import torch
+        gpus = max(1, torch.cuda.device_count())  # (counting devices does not initialise the GPU)
+    except Exception:  # noqa: BLE001
+        gpus = 1
+    return max(1, min(cores, 16 * gpus))
+
+
 def source_hash():
     """sha256 over the kernel sources the library is built from: ties a profiled traffic figure to the code it was
     measured on (profiles/r02_traffic.json carries the hash of the sources that were profiled)"""
@@ -196,10 +217,7 @@ def dist_setup(args):
 # c4 / c5: multi-surfel workloads
 # ---------------------------------------------------------------------------------------------------------------------
 def main_batched(args):
-    torch, dist, rank, world, backend, dev, stub = dist_setup(args)
-    from brdf_amd import dist as bdist
     from brdf_amd import synth
-
     S, n = {"c4": (65536, 4096), "c5": (1 << 20, 256)}[args.workload]
     if args.surfels:
         S = args.surfels
@@ -208,8 +226,11 @@ def main_batched(args):
     model, method = 2, (0 if args.entry == "dif" else 1)
     lb, ub = synth.bounds(model)
     cpu_base = None
-    if not args.no_cpu and world == 1 and not stub:  # before this process initialises the GPU: the workers are plain child processes
+    if (not args.no_cpu and int(os.environ.get("WORLD_SIZE", "1")) == 1 and os.environ.get("BRDF_BENCH_STUB") != "1"):
+        # before this process touches the GPU: the workers are plain child processes (numpy + ctypes, no torch, no HIP)
         cpu_base = cpu_baseline_batched(method, model, n, S)
+    torch, dist, rank, world, backend, dev, stub = dist_setup(args)
+    from brdf_amd import dist as bdist
     first, count = bdist.shard_range(S, rank, world)
     if stub:
         a_np, x_np, _ = synth.make_surfels(model, n, first=first, count=count)
