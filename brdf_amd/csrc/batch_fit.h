@@ -9,7 +9,7 @@
 namespace brdf {
 
 struct BatchFitArgs {
-  int method, model;
+  int method, model;  // method: BRDF_METHOD_* of include/brdf_levmar.h (0 dif, 1 bc_dif, 2 bc_der, 3 der)
   const double *d_angles, *d_x;
   int S, n;
   double *d_p;
@@ -35,6 +35,7 @@ struct BatchCtx {
   int has_opts, has_lb, has_ub;
   int multi;  // bc_dif: projected-gradient candidates per sweep (workgroup/wave-per-fit kernels)
   int lane_quorum, lane_maxwait;  // lane_fit.hip: lanes waiting for / rounds between two heavy rounds
+  int analytic;  // RQ_JAC rows from the model's analytic Jacobian (dlevmar_bc_der / dlevmar_der) instead of finite differences
   double opts[5], lb[kM], ub[kM];
 };
 

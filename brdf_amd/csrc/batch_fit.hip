@@ -12,14 +12,17 @@
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
+#include <vector>
 
+#include "../../include/brdf_levmar.h"
 #include "batch_fit.h"
 #include "stream_fit.h"
 
 namespace brdf {
 
+// internal METHOD: 0 dlevmar_dif, 1 dlevmar_bc_dif / dlevmar_bc_der (ctx.analytic), 2 dlevmar_der
 template <int METHOD>
-using BatchMachine = typename std::conditional<METHOD == 0, DifMachine<kM>, BcMachine<kM>>::type;
+using BatchMachine = typename std::conditional<METHOD == 0, DifMachine<kM>, typename std::conditional<METHOD == 1, BcMachine<kM>, DerMachine<kM>>::type>::type;
 
 // Occupancy: the LM step between two passes runs on one lane (~3700 cycles on gfx950) while the rest of the
 // workgroup waits, so throughput comes from OTHER workgroups on the same CU filling that time.  Measured: asking
@@ -89,10 +92,14 @@ __global__ __launch_bounds__(THREADS, (batch_waves_per_simd<THREADS, SPT>())) vo
   if (tid == 0) {
     const double *p0 = ctx.p + (size_t)fit * kM;
     const double *opts = ctx.has_opts ? ctx.opts : nullptr;
-    if constexpr (METHOD == 0)
+    if constexpr (METHOD == 0) {
       sm.start(p0, n, ctx.itmax, opts, 0, /*speculative=*/1);
-    else
+    } else if constexpr (METHOD == 1) {
       sm.start(p0, n, ctx.has_lb ? ctx.lb : nullptr, ctx.has_ub ? ctx.ub : nullptr, nullptr, ctx.itmax, opts, 0, ctx.multi);
+      sm.c.analytic_jac = ctx.analytic;
+    } else {
+      sm.start(p0, n, ctx.itmax, opts, 0);
+    }
   }
   __syncthreads();
 
@@ -108,7 +115,7 @@ __global__ __launch_bounds__(THREADS, (batch_waves_per_simd<THREADS, SPT>())) vo
   for (;;) {
     const int kind = sm.h.req.kind;
     if (kind == RQ_DONE) break;
-    if (first_wave) su.build(sm.h.req, /*need_base=*/METHOD != 0);  // (dif keeps f(p) per sample: a trial evaluates f at q only)
+    if (first_wave) su.build(sm.h.req, /*need_base=*/METHOD != 0, METHOD == 2 || (METHOD == 1 && ctx.analytic));  // (dif keeps f(p) per sample: a trial evaluates f at q only)
     __syncthreads();
     const PassUniforms<MODEL> &u = su;
     if constexpr (METHOD == 0) {  // commit what the machine decided about the previous trial (speculative protocol,
@@ -138,7 +145,7 @@ __global__ __launch_bounds__(THREADS, (batch_waves_per_simd<THREADS, SPT>())) vo
 
     switch (kind) {
     case RQ_EVAL:  // (each kernel is compiled with the request kinds its entry point issues only: register pressure)
-      if constexpr (METHOD == 1) {
+      if constexpr (METHOD != 0) {
 #pragma unroll
       for (int k = 0; k < SPT; ++k) {
         const double f = model_value<MODEL, FAST>(u, s0[k], pq[k]);
@@ -165,7 +172,7 @@ __global__ __launch_bounds__(THREADS, (batch_waves_per_simd<THREADS, SPT>())) vo
       }
       break;
     case RQ_SCALED:
-      if constexpr (METHOD == 1) {
+      if constexpr (METHOD == 1) {  // (only dlevmar_bc_*'s overflow guard issues it)
 #pragma unroll
       for (int k = 0; k < SPT; ++k) {
         const double f = model_value<MODEL, FAST>(u, s0[k], pq[k]);
@@ -176,11 +183,14 @@ __global__ __launch_bounds__(THREADS, (batch_waves_per_simd<THREADS, SPT>())) vo
       }
       break;
     case RQ_JAC:
-      if constexpr (METHOD == 1) {
+      if constexpr (METHOD != 0) {
 #pragma unroll
       for (int k = 0; k < SPT; ++k) {
         double f0 = 0.0, j[kM];
-        model_fd_row<MODEL, FAST>(u, s0[k], pq[k], true, f0, 0.0, false, j);
+        if (METHOD == 2 || u.analytic)  // dlevmar_der / dlevmar_bc_der: the model's analytic Jacobian
+          model_an_row<MODEL, FAST>(u, s0[k], pq[k], f0, j);
+        else
+          model_fd_row<MODEL, FAST>(u, s0[k], pq[k], true, f0, 0.0, false, j);
         double e = sx[k] - f0;
         if (!ok[k]) e = j[0] = j[1] = j[2] = 0.0;
         acc_normal_eq(j, e, acc, acc + kNL);
@@ -500,13 +510,13 @@ using BatchFn = void (*)(BatchCtx);
 
 template <int THREADS, int SPT>
 BatchFn pick(int model, int method, bool fast) {
-  static const BatchFn table[2][MODEL_COUNT][2] = {
-      {{batch_fit_kernel<0, 0, false, THREADS, SPT>, batch_fit_kernel<0, 1, false, THREADS, SPT>},
-       {batch_fit_kernel<1, 0, false, THREADS, SPT>, batch_fit_kernel<1, 1, false, THREADS, SPT>},
-       {nullptr, nullptr}},  // Ward's prepared path has no domain restriction: no exact twin needed
-      {{batch_fit_kernel<0, 0, true, THREADS, SPT>, batch_fit_kernel<0, 1, true, THREADS, SPT>},
-       {batch_fit_kernel<1, 0, true, THREADS, SPT>, batch_fit_kernel<1, 1, true, THREADS, SPT>},
-       {batch_fit_kernel<2, 0, true, THREADS, SPT>, batch_fit_kernel<2, 1, true, THREADS, SPT>}},
+  static const BatchFn table[2][MODEL_COUNT][3] = {
+      {{batch_fit_kernel<0, 0, false, THREADS, SPT>, batch_fit_kernel<0, 1, false, THREADS, SPT>, batch_fit_kernel<0, 2, false, THREADS, SPT>},
+       {batch_fit_kernel<1, 0, false, THREADS, SPT>, batch_fit_kernel<1, 1, false, THREADS, SPT>, batch_fit_kernel<1, 2, false, THREADS, SPT>},
+       {nullptr, nullptr, nullptr}},  // Ward's prepared path has no domain restriction: no exact twin needed
+      {{batch_fit_kernel<0, 0, true, THREADS, SPT>, batch_fit_kernel<0, 1, true, THREADS, SPT>, batch_fit_kernel<0, 2, true, THREADS, SPT>},
+       {batch_fit_kernel<1, 0, true, THREADS, SPT>, batch_fit_kernel<1, 1, true, THREADS, SPT>, batch_fit_kernel<1, 2, true, THREADS, SPT>},
+       {batch_fit_kernel<2, 0, true, THREADS, SPT>, batch_fit_kernel<2, 1, true, THREADS, SPT>, batch_fit_kernel<2, 2, true, THREADS, SPT>}},
   };
   return table[fast ? 1 : 0][model][method];
 }
@@ -625,8 +635,11 @@ static bool big_path_enabled() {
 
 namespace {
 int batch_fit_launches(const BatchFitArgs &a, const Geometry &g, int *flags, int *queue) {
+  // the C ABI's method -> the kernels' machine (0 Dif, 1 Bc, 2 Der) + where the Jacobian rows come from
+  const int method = (a.method == BRDF_METHOD_BC_DER) ? 1 : (a.method == BRDF_METHOD_DER ? 2 : a.method);
   BatchCtx c;
   memset(&c, 0, sizeof c);
+  c.analytic = (a.method == BRDF_METHOD_BC_DER || a.method == BRDF_METHOD_DER) ? 1 : 0;
   c.angles = a.d_angles;
   c.x = a.d_x;
   c.p = a.d_p;
@@ -649,33 +662,73 @@ int batch_fit_launches(const BatchFitArgs &a, const Geometry &g, int *flags, int
   }
   HIP_OK(hipMemsetAsync(queue, 0, 2 * sizeof(int), a.stream));
   const bool fast = brdf_fast_path_enabled() || a.model == MODEL_WARD;
-  if (a.n <= kLaneMaxN && a.method == 1 && lane_path_enabled()) return lane_fit_enqueue(a.model, fast, c, queue, a.stream);
-  if (a.n <= kRowLanes && rows_path_enabled(a.method)) return rows_enqueue(a, c, fast, queue);
-  if (g.threads == 512 && big_path_enabled()) {  // 1024 < n <= 4096: control wave + seven sample waves per fit (resident_fit.hip)
+  if (a.n <= kLaneMaxN && method == 1 && lane_path_enabled()) return lane_fit_enqueue(a.model, fast, c, queue, a.stream);
+  if (a.n <= kRowLanes && method != 2 && !c.analytic && rows_path_enabled(method)) {
+    BatchFitArgs b = a;
+    b.method = method;
+    return rows_enqueue(b, c, fast, queue);
+  }
+  if (g.threads == 512 && (big_path_enabled() || method == 2 || c.analytic)) {  // 1024 < n <= 4096: eight waves per fit (resident_fit.hip)
     c.multi = pg_candidates();
     if (!fast) HIP_OK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(flags), kNeedsExact, (size_t)a.S, a.stream));
-    return resident_batch_enqueue(a.model, a.method, fast, c, a.stream);
+    return resident_batch_enqueue(a.model, method, fast, c, a.stream);
   }
   const dim3 grid(a.S), block(g.threads);
   if (fast) {
-    hipLaunchKernelGGL(kernel_for(g, a.model, a.method, true), grid, block, 0, a.stream, c);
+    hipLaunchKernelGGL(kernel_for(g, a.model, method, true), grid, block, 0, a.stream, c);
     HIP_OK(hipGetLastError());
     if (a.model != MODEL_WARD) {  // fits with a cosine <= 0 marked themselves: second launch on the exact path
-      hipLaunchKernelGGL(kernel_for(g, a.model, a.method, false), grid, block, 0, a.stream, c);
+      hipLaunchKernelGGL(kernel_for(g, a.model, method, false), grid, block, 0, a.stream, c);
       HIP_OK(hipGetLastError());
     }
   } else {
     // BRDF_HIP_EXACT_POW=1: mark every fit for the exact kernel
     HIP_OK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(flags), kNeedsExact, (size_t)a.S, a.stream));
-    hipLaunchKernelGGL(kernel_for(g, a.model, a.method, false), grid, block, 0, a.stream, c);
+    hipLaunchKernelGGL(kernel_for(g, a.model, method, false), grid, block, 0, a.stream, c);
     HIP_OK(hipGetLastError());
   }
   return 0;
 }
 }  // namespace
 
+// n > 4096 samples per fit: a fit no longer fits one workgroup's registers + LDS, but it fits the CHIP -- the fits run one
+// after the other through the single-fit path (resident regime up to #CUs * 4096 samples, the launch chain beyond), each
+// using every CU.  The starting points travel to the host and the results back: synchronous on a.stream.
+namespace {
+int batch_of_large_fits(const BatchFitArgs &a) {
+  std::vector<double> p((size_t)a.S * kM), info((size_t)a.S * kInfoSz);
+  std::vector<int> ret(a.S);
+  HIP_OK(hipMemcpyAsync(p.data(), a.d_p, sizeof(double) * p.size(), hipMemcpyDeviceToHost, a.stream));
+  HIP_OK(hipStreamSynchronize(a.stream));
+  for (int s = 0; s < a.S; ++s) {
+    StreamFitArgs f;
+    f.method = (a.method == BRDF_METHOD_BC_DER) ? 1 : (a.method == BRDF_METHOD_DER ? 2 : a.method);
+    f.analytic = (a.method == BRDF_METHOD_BC_DER || a.method == BRDF_METHOD_DER) ? 1 : 0;
+    f.model = a.model;
+    f.d_angles = a.d_angles + (size_t)s * 3 * a.n;
+    f.d_x = a.d_x + (size_t)s * a.n;
+    f.n = a.n;
+    f.p = p.data() + (size_t)s * kM;
+    f.lb = a.lb;
+    f.ub = a.ub;
+    f.dscl = nullptr;
+    f.itmax = a.itmax;
+    f.opts = a.opts;
+    f.info = info.data() + (size_t)s * kInfoSz;
+    f.covar = nullptr;
+    f.stream = a.stream;
+    ret[s] = stream_fit_run(f);
+  }
+  HIP_OK(hipMemcpyAsync(a.d_p, p.data(), sizeof(double) * p.size(), hipMemcpyHostToDevice, a.stream));
+  if (a.d_info) HIP_OK(hipMemcpyAsync(a.d_info, info.data(), sizeof(double) * info.size(), hipMemcpyHostToDevice, a.stream));
+  if (a.d_ret) HIP_OK(hipMemcpyAsync(a.d_ret, ret.data(), sizeof(int) * ret.size(), hipMemcpyHostToDevice, a.stream));
+  HIP_OK(hipStreamSynchronize(a.stream));  // (the host vectors above are about to go away)
+  return 0;
+}
+}  // namespace
+
 int batch_fit_enqueue(const BatchFitArgs &a) {
-  if (a.model < 0 || a.model >= MODEL_COUNT || (a.method != 0 && a.method != 1)) {
+  if (a.model < 0 || a.model >= MODEL_COUNT || a.method < 0 || a.method > BRDF_METHOD_DER) {
     set_error("brdf_hip_fit_batch_dev(): unknown model %d / method %d", a.model, a.method);
     return kLmError;
   }
@@ -684,13 +737,8 @@ int batch_fit_enqueue(const BatchFitArgs &a) {
     return kLmError;
   }
   Geometry g;
-  if (!geometry_for(a.n, &g)) {
-    set_error("brdf_hip_fit_batch_dev(): n = %d exceeds the register-resident limit of 4096 samples per fit; "
-              "use brdf_hip_fit_dev (streamed regime) for large fits",
-              a.n);
-    return kLmError;
-  }
-  if (a.method == 1 && a.lb && a.ub)
+  if (!geometry_for(a.n, &g)) return batch_of_large_fits(a);  // n > 4096: one fit after the other, each spread over the chip
+  if ((a.method == 1 || a.method == BRDF_METHOD_BC_DER) && a.lb && a.ub)
     for (int i = 0; i < kM; ++i)
       if (a.lb[i] > a.ub[i]) {  // lmbc_core.c:451-454
         set_error("dlevmar_bc_dif(): at least one lower bound exceeds the upper one");

@@ -206,13 +206,8 @@ int dlevmar_der(void (*func)(double *, double *, int, int, void *), void (*jacf)
   }
   Opts4 o4(opts);
   opts = o4.ptr;
-  if (is_registered(func) && jacf == &BRDFJac_hip) {  // a built-in model with its own analytic Jacobian: resident regime
-    double keep[8];
-    for (int i = 0; i < m && i < 8; ++i) keep[i] = p[i];
-    const int r = host_fit(2, "dlevmar_der", func, p, x, m, n, nullptr, nullptr, nullptr, itmax, opts, info, covar, adata, 1);
-    if (r != kStreamNoDevicePath) return r;
-    for (int i = 0; i < m && i < 8; ++i) p[i] = keep[i];  // too large for the chip: BRDFFunc_hip / BRDFJac_hip as plain callbacks
-  }
+  if (is_registered(func) && jacf == &BRDFJac_hip)  // a built-in model with its own analytic Jacobian: all on the device
+    return host_fit(2, "dlevmar_der", func, p, x, m, n, nullptr, nullptr, nullptr, itmax, opts, info, covar, adata, 1);
   return generic_fit_run(2, func, jacf, p, x, m, n, nullptr, nullptr, nullptr, itmax, opts, info, covar, adata);
 }
 
@@ -428,8 +423,7 @@ int brdf_hip_fit_dev(int method, int model, const double *d_angles, const double
   a.info = info;
   a.covar = covar;
   a.stream = static_cast<hipStream_t>(stream);
-  const int r = stream_fit_run(a);
-  return r == kStreamNoDevicePath ? LM_ERROR : r;
+  return stream_fit_run(a);
 }
 
 int brdf_hip_fit_batch_dev(int method, int model, const double *d_angles, const double *d_x, int S, int n,

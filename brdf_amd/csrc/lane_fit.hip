@@ -98,6 +98,7 @@ __global__ __launch_bounds__(kWave, W) void lane_fit_kernel(BatchCtx ctx, int *q
           if (FAST) ctx.flags[f] = bad ? kNeedsExact : 0;
           if (!(FAST && bad)) {
             m.start(ctx.p + (size_t)f * kM, n, lb, ub, nullptr, ctx.itmax, opts, 0, 1);
+            m.c.analytic_jac = ctx.analytic;
             if (m.h.req.kind == RQ_DONE) {  // refused by start() (n < m, inconsistent box): lmbc_core.c:440-454
               if (ctx.ret) ctx.ret[f] = kLmError;
               if (ctx.info)
@@ -125,12 +126,15 @@ __global__ __launch_bounds__(kWave, W) void lane_fit_kernel(BatchCtx ctx, int *q
       if (kind == RQ_JAC) {
         if (heavy) {  // lmbc_core.c:595-615: for l = n-1..0 { jtj[i][j] += row[j]*row[i]; jte[i] += row[i]*e[l] }
           PassUniforms<MODEL> u;
-          u.build(r, true, false);
+          u.build(r, true, ctx.analytic != 0);
           for (int l = n; l-- > 0;) {
             const double *d = sp + (size_t)l * NP * kWave;
             const Prep q{d[kWave], NP == 4 ? d[2 * kWave] : 0.0};
             double f0 = 0.0, j[kM];
-            model_fd_row<MODEL, FAST>(u, d[0], q, true, f0, 0.0, false, j);
+            if (ctx.analytic)  // dlevmar_bc_der: the model's analytic Jacobian (wave-uniform branch)
+              model_an_row<MODEL, FAST>(u, d[0], q, f0, j);
+            else
+              model_fd_row<MODEL, FAST>(u, d[0], q, true, f0, 0.0, false, j);
             const double e = d[(NP - 1) * kWave] - f0;
             acc_normal_eq(j, e, s, s + kNL);
           }

@@ -557,10 +557,14 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
     if (wave == 0) {
       const double *p0 = bctx.p + (size_t)fit * kM;
       const double *opts = bctx.has_opts ? bctx.opts : nullptr;
-      if constexpr (METHOD == 0)
+      if constexpr (METHOD == 0) {
         sm.start(p0, n, bctx.itmax, opts, 0, /*speculative=*/1);
-      else
+      } else if constexpr (METHOD == 1) {
         sm.start(p0, n, bctx.has_lb ? bctx.lb : nullptr, bctx.has_ub ? bctx.ub : nullptr, nullptr, bctx.itmax, opts, 0, bctx.multi);
+        sm.c.analytic_jac = bctx.analytic;
+      } else {
+        sm.start(p0, n, bctx.itmax, opts, 0);
+      }
     }
   } else {  // the started machine, written by the host before the launch
     const unsigned *src = reinterpret_cast<const unsigned *>(ctx.machine0);
@@ -1017,15 +1021,18 @@ int resident_batch_mm(bool fast, const BatchCtx &c, hipStream_t stream) {
 }  // namespace
 
 int resident_batch_enqueue(int model, int method, bool fast, const BatchCtx &c, hipStream_t stream) {
-  switch (model * 2 + method) {
+  switch (model * 3 + method) {
 #ifndef BRDF_DEV_WARD_ONLY
   case 0: return resident_batch_mm<0, 0>(fast, c, stream);
   case 1: return resident_batch_mm<0, 1>(fast, c, stream);
-  case 2: return resident_batch_mm<1, 0>(fast, c, stream);
-  case 3: return resident_batch_mm<1, 1>(fast, c, stream);
+  case 2: return resident_batch_mm<0, 2>(fast, c, stream);
+  case 3: return resident_batch_mm<1, 0>(fast, c, stream);
+  case 4: return resident_batch_mm<1, 1>(fast, c, stream);
+  case 5: return resident_batch_mm<1, 2>(fast, c, stream);
 #endif
-  case 4: return resident_batch_mm<2, 0>(fast, c, stream);
-  default: return resident_batch_mm<2, 1>(fast, c, stream);
+  case 6: return resident_batch_mm<2, 0>(fast, c, stream);
+  case 7: return resident_batch_mm<2, 1>(fast, c, stream);
+  default: return resident_batch_mm<2, 2>(fast, c, stream);
   }
 }
 

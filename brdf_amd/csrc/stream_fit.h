@@ -21,6 +21,7 @@ constexpr int kStreamWavesPerSimd = 2; // 8 waves per CU: the register allocator
 union MachineUnion {
   DifMachine<kM> dif;
   BcMachine<kM> bc;
+  DerMachine<kM> der;
   __host__ __device__ MachineUnion() {}
 };
 
@@ -71,7 +72,6 @@ struct StreamFitArgs {
   double *info, *covar;
   hipStream_t stream;
 };
-constexpr int kStreamNoDevicePath = -1000;  // stream_fit_run: method 2 (dlevmar_der) could not run in the resident regime
 int stream_fit_run(const StreamFitArgs &a);
 
 struct FitStats {

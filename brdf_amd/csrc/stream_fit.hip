@@ -33,15 +33,18 @@ namespace brdf {
 // ---------------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------------
+// METHOD 0 dlevmar_dif, 1 dlevmar_bc_dif / bc_der, 2 dlevmar_der (the model's analytic Jacobian, lm_core.c:64-432)
 template <int METHOD>
-using MachineOf = typename std::conditional<METHOD == 0, DifMachine<kM>, BcMachine<kM>>::type;
+using MachineOf = typename std::conditional<METHOD == 0, DifMachine<kM>, typename std::conditional<METHOD == 1, BcMachine<kM>, DerMachine<kM>>::type>::type;
 
 template <int METHOD>
 __device__ __forceinline__ MachineOf<METHOD> *machine_slot(StreamCtx *ctx, int which) {
   if constexpr (METHOD == 0)
     return &ctx->m[which].dif;
-  else
+  else if constexpr (METHOD == 1)
     return &ctx->m[which].bc;
+  else
+    return &ctx->m[which].der;
 }
 
 template <int METHOD>
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(kStreamThreads, kStreamWavesPerSimd) void stream_pa
     if constexpr (METHOD == 1)
       su.build(sm.h.req, true, sm.c.analytic_jac != 0);
     else
-      su.build(sm.h.req);
+      su.build(sm.h.req, true, METHOD == 2);
   }
   STAMP();
   if (blockIdx.x == 0) {  // persist the advanced machine for the next launch
@@ -481,13 +484,13 @@ thread_local Workspace g_ws;
 
 using PassFn = void (*)(StreamCtx *, int);
 PassFn pass_kernel(int model, int method, bool fast) {
-  static const PassFn table[2][MODEL_COUNT][2] = {
-      {{stream_pass<0, 0, false>, stream_pass<0, 1, false>},
-       {stream_pass<1, 0, false>, stream_pass<1, 1, false>},
-       {stream_pass<2, 0, false>, stream_pass<2, 1, false>}},
-      {{stream_pass<0, 0, true>, stream_pass<0, 1, true>},
-       {stream_pass<1, 0, true>, stream_pass<1, 1, true>},
-       {stream_pass<2, 0, true>, stream_pass<2, 1, true>}},
+  static const PassFn table[2][MODEL_COUNT][3] = {
+      {{stream_pass<0, 0, false>, stream_pass<0, 1, false>, stream_pass<0, 2, false>},
+       {stream_pass<1, 0, false>, stream_pass<1, 1, false>, stream_pass<1, 2, false>},
+       {stream_pass<2, 0, false>, stream_pass<2, 1, false>, stream_pass<2, 2, false>}},
+      {{stream_pass<0, 0, true>, stream_pass<0, 1, true>, stream_pass<0, 2, true>},
+       {stream_pass<1, 0, true>, stream_pass<1, 1, true>, stream_pass<1, 2, true>},
+       {stream_pass<2, 0, true>, stream_pass<2, 1, true>, stream_pass<2, 2, true>}},
   };
   return table[fast ? 1 : 0][model][method];
 }
@@ -539,6 +542,13 @@ static int stream_fit_attempt(const StreamFitArgs &a, bool fast, bool *retry_exa
     m.start(a.p, a.n, a.itmax, a.opts, a.covar != nullptr);
     if (m.h.req.kind == RQ_DONE) {
       set_error("dlevmar_dif(): cannot solve a problem with fewer measurements [%d] than unknowns [%d]", a.n, kM);
+      return kLmError;
+    }
+  } else if (a.method == 2) {
+    DerMachine<kM> &m = h.m[0].der;
+    m.start(a.p, a.n, a.itmax, a.opts, a.covar != nullptr);
+    if (m.h.req.kind == RQ_DONE) {
+      set_error("dlevmar_der(): cannot solve a problem with fewer measurements [%d] than unknowns [%d]", a.n, kM);
       return kLmError;
     }
   } else {
@@ -678,10 +688,6 @@ int stream_fit_run(const StreamFitArgs &a) {
     }
     for (int i = 0; i < kM; ++i) a.p[i] = p_keep[i];
     g_last_was_resident = false;
-  }
-  if (a.method == 2) {  // dlevmar_der has no launch-chain kernels: the caller (capi.hip) goes through the host-callback path
-    set_error("dlevmar_der on the device needs the resident regime (n <= #CUs * 4096, GPU not shared)");
-    return kStreamNoDevicePath;
   }
   bool retry = false;
   int ret = stream_fit_attempt(a, brdf_fast_path_enabled(), &retry);

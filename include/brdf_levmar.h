@@ -41,8 +41,8 @@ struct brdf_extra_data {
 
 enum { BRDF_MODEL_PHONG = 0, BRDF_MODEL_BLINN_PHONG = 1, BRDF_MODEL_WARD = 2 };
 enum { BRDF_METHOD_DIF = 0, BRDF_METHOD_BC_DIF = 1,
-       BRDF_METHOD_BC_DER = 2, /* brdf_hip_fit_dev only: dlevmar_bc_der with the model's analytic Jacobian */
-       BRDF_METHOD_DER = 3     /* brdf_hip_fit_dev only: dlevmar_der with it (n <= #CUs * 4096: resident regime only) */ };
+       BRDF_METHOD_BC_DER = 2, /* device entry points: dlevmar_bc_der with the model's analytic Jacobian (BRDFJac_hip's) */
+       BRDF_METHOD_DER = 3     /* device entry points: dlevmar_der with it */ };
 
 /* ---- drop-in solver entry points ----------------------------------------------------------------- */
 
@@ -135,8 +135,10 @@ int brdf_hip_fit_dev(int method, int model, const double *d_angles, const double
  * (brdfdata.cpp:1195-1220) as one call.  All array arguments are DEVICE pointers:
  *   d_angles[S][3][n], d_x[S][n], d_p[S][3] (in: starting points, out: fitted), d_info[S][10] (or NULL),
  *   d_ret[S] ints (or NULL; per-fit return value).
- * lb/ub/opts are HOST pointers shared by all fits.  Asynchronous on `stream`; returns 0 on successful
- * enqueue, LM_ERROR on bad arguments / launch failure. */
+ * lb/ub/opts are HOST pointers shared by all fits.  method: any BRDF_METHOD_*.  n <= 4096: one launch (or two), a fit
+ * per lane / wavefront / workgroup by size, asynchronous on `stream`.  n > 4096: the fits run one after the other, each
+ * spread over the whole chip (the single-fit regimes of brdf_hip_fit_dev), and the call returns when they are done.
+ * Returns 0 on success, LM_ERROR on bad arguments / launch failure. */
 int brdf_hip_fit_batch_dev(int method, int model, const double *d_angles, const double *d_x, int S, int n,
                            double *d_p, const double *lb, const double *ub, int itmax,
                            const double *opts, double *d_info, int *d_ret, void *stream);
