@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BRDF_HIP_LIB") or os.path.join(_HERE, "libbrdf_hip.so")
 
 D = C.POINTER(C.c_double)
+F = C.POINTER(C.c_float)
 I = C.POINTER(C.c_int)
 MODEL_FUNC = C.CFUNCTYPE(None, D, D, C.c_int, C.c_int, C.c_void_p)
 
@@ -32,6 +33,15 @@ ABI = {
     "dlevmar_corcoef": (C.c_double, [D, C.c_int, C.c_int, C.c_int]),
     "dlevmar_R2": (C.c_double, [C.c_void_p, D, D, C.c_int, C.c_int, C.c_void_p]),
     "dAx_eq_b_LU_noLapack": (C.c_int, [D, D, D, C.c_int]),
+    "slevmar_dif": (C.c_int, [C.c_void_p, F, F, C.c_int, C.c_int, C.c_int, F, F, F, F, C.c_void_p]),
+    "slevmar_bc_dif": (C.c_int, [C.c_void_p, F, F, C.c_int, C.c_int, F, F, F, C.c_int, F, F, F, F, C.c_void_p]),
+    "slevmar_der": (C.c_int, [C.c_void_p, C.c_void_p, F, F, C.c_int, C.c_int, C.c_int, F, F, F, F, C.c_void_p]),
+    "slevmar_bc_der": (C.c_int, [C.c_void_p, C.c_void_p, F, F, C.c_int, C.c_int, F, F, F, C.c_int, F, F, F, F, C.c_void_p]),
+    "slevmar_chkjac": (None, [C.c_void_p, C.c_void_p, F, C.c_int, C.c_int, C.c_void_p, F]),
+    "slevmar_stddev": (C.c_float, [F, C.c_int, C.c_int]),
+    "slevmar_corcoef": (C.c_float, [F, C.c_int, C.c_int, C.c_int]),
+    "slevmar_R2": (C.c_float, [C.c_void_p, F, F, C.c_int, C.c_int, C.c_void_p]),
+    "sAx_eq_b_LU_noLapack": (C.c_int, [F, F, F, C.c_int]),
     "brdf_hip_register_model": (C.c_int, [C.c_void_p]),
     "brdf_hip_unregister_model": (C.c_int, [C.c_void_p]),
     "BRDFFunc_hip": (None, [D, D, C.c_int, C.c_int, C.c_void_p]),

@@ -25,6 +25,11 @@ int model_eval_run(int model, const double *d_angles, int n, const double *p, do
 int model_jac_run(int model, const double *d_angles, int n, const double *p, double *d_jac, hipStream_t stream);
 int chkjac_err_run(const double *fvec, const double *fjac, const double *fvecp, const double *p, int m, int n, double *err);
 int r2_run(const double *x, const double *hx, int n, double *r2);
+int generic_fit_run_f(int method, void (*func)(float *, float *, int, int, void *), void (*jacf)(float *, float *, int, int, void *),
+                      float *p, float *x, int m, int n, float *lb, float *ub, float *dscl, int itmax, float *opts, float *info,
+                      float *covar, void *adata);
+int chkjac_err_run_f(const float *fvec, const float *fjac, const float *fvecp, const float *p, int m, int n, float *err);
+int r2_run_f(const float *x, const float *hx, int n, float *r2);
 }
 
 using namespace brdf;
@@ -177,6 +182,83 @@ int host_fit(int method, const char *who, model_func_t func, double *p, double *
 
 }  // namespace
 
+namespace {
+/* Axb_core.c:1197-1270 for a run-time m: Crout LU with implicit row scaling + partial pivoting, zero pivot -> LmLimits<Real>::eps(),
+ * forward and back substitution.  Same operations in the same order as lm_machine.h: lu_solve<M> (which the fitter uses in
+ * registers and which the reference's known answers pin bit for bit). */
+template <class Real>
+static int lu_noLapack(Real *A, Real *B, Real *x, int m, const char *who) {
+  if (!A) return 1;  // Axb_core.c:1149-1157: "release the retained buffer" -- there is none here
+  if (!B || !x || m <= 0) {
+    set_error("%s(): bad arguments", who);
+    return 0;
+  }
+  std::vector<Real> a(A, A + (size_t)m * m), scale(m);
+  std::vector<int> perm(m);
+  for (int i = 0; i < m; ++i) x[i] = B[i];
+  for (int i = 0; i < m; ++i) {
+    Real big = Real(0.0);
+    for (int j = 0; j < m; ++j) {
+      const Real t = std::fabs(a[(size_t)i * m + j]);
+      if (t > big) big = t;
+    }
+    if (big == Real(0.0)) {
+      fprintf(stderr, "Singular matrix A in %s()!\n", who);  // Axb_core.c:1203-1206
+      return 0;
+    }
+    scale[i] = Real(1.0) / big;
+  }
+  for (int j = 0; j < m; ++j) {
+    int pivot = j;
+    Real big = Real(0.0);
+    for (int i = 0; i < j; ++i) {
+      Real s = a[(size_t)i * m + j];
+      for (int k = 0; k < i; ++k) s -= a[(size_t)i * m + k] * a[(size_t)k * m + j];
+      a[(size_t)i * m + j] = s;
+    }
+    for (int i = j; i < m; ++i) {
+      Real s = a[(size_t)i * m + j];
+      for (int k = 0; k < j; ++k) s -= a[(size_t)i * m + k] * a[(size_t)k * m + j];
+      a[(size_t)i * m + j] = s;
+      const Real t = scale[i] * std::fabs(s);
+      if (t >= big) {
+        big = t;
+        pivot = i;
+      }
+    }
+    if (j != pivot) {
+      for (int k = 0; k < m; ++k) std::swap(a[(size_t)pivot * m + k], a[(size_t)j * m + k]);
+      scale[pivot] = scale[j];
+    }
+    perm[j] = pivot;
+    if (a[(size_t)j * m + j] == Real(0.0)) a[(size_t)j * m + j] = LmLimits<Real>::eps();
+    if (j != m - 1) {
+      const Real t = Real(1.0) / a[(size_t)j * m + j];
+      for (int i = j + 1; i < m; ++i) a[(size_t)i * m + j] *= t;
+    }
+  }
+  int first = 0;
+  for (int i = 0; i < m; ++i) {
+    const int ip = perm[i];
+    Real s = x[ip];
+    x[ip] = x[i];
+    if (first != 0) {
+      for (int jj = first - 1; jj < i; ++jj) s -= a[(size_t)i * m + jj] * x[jj];
+    } else if (s != Real(0.0)) {
+      first = i + 1;
+    }
+    x[i] = s;
+  }
+  for (int i = m - 1; i >= 0; --i) {
+    Real s = x[i];
+    for (int j = i + 1; j < m; ++j) s -= a[(size_t)i * m + j] * x[j];
+    x[i] = s / a[(size_t)i * m + i];
+  }
+  return 1;
+}
+
+}  // namespace
+
 extern "C" {
 
 int dlevmar_dif(void (*func)(double *, double *, int, int, void *), double *p, double *x, int m, int n, int itmax,
@@ -247,77 +329,76 @@ double dlevmar_R2(void (*func)(double *, double *, int, int, void *), double *p,
   return r2;
 }
 
-/* Axb_core.c:1197-1270 for a run-time m: Crout LU with implicit row scaling + partial pivoting, zero pivot -> DBL_EPSILON,
- * forward and back substitution.  Same operations in the same order as lm_machine.h: lu_solve<M> (which the fitter uses in
- * registers and which the reference's known answers pin bit for bit). */
-int dAx_eq_b_LU_noLapack(double *A, double *B, double *x, int m) {
-  if (!A) return 1;  // Axb_core.c:1149-1157: "release the retained buffer" -- there is none here
-  if (!B || !x || m <= 0) {
-    set_error("dAx_eq_b_LU_noLapack(): bad arguments");
-    return 0;
+int dAx_eq_b_LU_noLapack(double *A, double *B, double *x, int m) { return lu_noLapack<double>(A, B, x, m, "dAx_eq_b_LU_noLapack"); }
+int sAx_eq_b_LU_noLapack(float *A, float *B, float *x, int m) { return lu_noLapack<float>(A, B, x, m, "sAx_eq_b_LU_noLapack"); }
+
+/* ---- the single-precision twins, levmar/levmar.h:208-310 (instantiated in the reference from the same *_core.c files with
+ * LM_REAL = float, lm.c:43-63; here: the same machines and kernels with Real = float).  The callbacks are the caller's host
+ * code and run on the host; everything n-sized around them runs on the device, in float, in the reference's summation
+ * order for n*m <= 65536.  (There is no registered-model shortcut: the BRDF application is double-only.) */
+int slevmar_dif(void (*func)(float *, float *, int, int, void *), float *p, float *x, int m, int n, int itmax, float *opts,
+                float *info, float * /*work*/, float *covar, void *adata) {
+  return generic_fit_run_f(0, func, nullptr, p, x, m, n, nullptr, nullptr, nullptr, itmax, opts, info, covar, adata);
+}
+int slevmar_bc_dif(void (*func)(float *, float *, int, int, void *), float *p, float *x, int m, int n, float *lb, float *ub,
+                   float *dscl, int itmax, float *opts, float *info, float * /*work*/, float *covar, void *adata) {
+  return generic_fit_run_f(1, func, nullptr, p, x, m, n, lb, ub, dscl, itmax, opts, info, covar, adata);
+}
+int slevmar_der(void (*func)(float *, float *, int, int, void *), void (*jacf)(float *, float *, int, int, void *), float *p, float *x,
+                int m, int n, int itmax, float *opts, float *info, float * /*work*/, float *covar, void *adata) {
+  if (!jacf) {  // lm_core.c:126-130
+    set_error("No function specified for computing the Jacobian in slevmar_der(). If no such function is available, use "
+              "slevmar_dif() rather than slevmar_der()");
+    return LM_ERROR;
   }
-  std::vector<double> a(A, A + (size_t)m * m), scale(m);
-  std::vector<int> perm(m);
-  for (int i = 0; i < m; ++i) x[i] = B[i];
-  for (int i = 0; i < m; ++i) {
-    double big = 0.0;
-    for (int j = 0; j < m; ++j) {
-      const double t = fabs(a[(size_t)i * m + j]);
-      if (t > big) big = t;
-    }
-    if (big == 0.0) {
-      fprintf(stderr, "Singular matrix A in dAx_eq_b_LU_noLapack()!\n");  // Axb_core.c:1203-1206
-      return 0;
-    }
-    scale[i] = 1.0 / big;
+  float o5[5] = {0, 0, 0, 0, (float)LM_DIFF_DELTA};  // four documented elements (see Opts4)
+  if (opts)
+    for (int i = 0; i < 4; ++i) o5[i] = opts[i];
+  return generic_fit_run_f(2, func, jacf, p, x, m, n, nullptr, nullptr, nullptr, itmax, opts ? o5 : nullptr, info, covar, adata);
+}
+int slevmar_bc_der(void (*func)(float *, float *, int, int, void *), void (*jacf)(float *, float *, int, int, void *), float *p,
+                   float *x, int m, int n, float *lb, float *ub, float *dscl, int itmax, float *opts, float *info, float * /*work*/,
+                   float *covar, void *adata) {
+  if (!jacf) {  // lmbc_core.c:445-449
+    set_error("No function specified for computing the Jacobian in slevmar_bc_der(). If no such function is available, "
+              "use slevmar_bc_dif() rather than slevmar_bc_der()");
+    return LM_ERROR;
   }
+  float o5[5] = {0, 0, 0, 0, (float)LM_DIFF_DELTA};
+  if (opts)
+    for (int i = 0; i < 4; ++i) o5[i] = opts[i];
+  return generic_fit_run_f(1, func, jacf, p, x, m, n, lb, ub, dscl, itmax, opts ? o5 : nullptr, info, covar, adata);
+}
+float slevmar_stddev(float *covar, int m, int i) { return (float)sqrt(covar[i * m + i]); }  /* misc_core.c:598-602 */
+float slevmar_corcoef(float *covar, int m, int i, int j) { return (float)(covar[i * m + j] / sqrt(covar[i * m + i] * covar[j * m + j])); }
+float slevmar_R2(void (*func)(float *, float *, int, int, void *), float *p, float *x, int m, int n, void *adata) {
+  if (!func || !p || m <= 0 || n <= 0) {
+    set_error("slevmar_R2(): bad arguments");
+    return NAN;
+  }
+  std::vector<float> hx(n);
+  (*func)(p, hx.data(), m, n, adata);
+  float r2 = NAN;
+  (void)r2_run_f(x, hx.data(), n, &r2);
+  return r2;
+}
+void slevmar_chkjac(void (*func)(float *, float *, int, int, void *), void (*jacf)(float *, float *, int, int, void *), float *p, int m,
+                    int n, void *adata, float *err) {
+  if (!func || !jacf || !p || !err || m <= 0 || n <= 0) {
+    set_error("slevmar_chkjac(): bad arguments");
+    return;
+  }
+  std::vector<float> fvec(n), fjac((size_t)n * m), pp(m), fvecp(n);
+  const float eps = sqrtf(FLT_EPSILON);
+  (*func)(p, fvec.data(), m, n, adata);
+  (*jacf)(p, fjac.data(), m, n, adata);
   for (int j = 0; j < m; ++j) {
-    int pivot = j;
-    double big = 0.0;
-    for (int i = 0; i < j; ++i) {
-      double s = a[(size_t)i * m + j];
-      for (int k = 0; k < i; ++k) s -= a[(size_t)i * m + k] * a[(size_t)k * m + j];
-      a[(size_t)i * m + j] = s;
-    }
-    for (int i = j; i < m; ++i) {
-      double s = a[(size_t)i * m + j];
-      for (int k = 0; k < j; ++k) s -= a[(size_t)i * m + k] * a[(size_t)k * m + j];
-      a[(size_t)i * m + j] = s;
-      const double t = scale[i] * fabs(s);
-      if (t >= big) {
-        big = t;
-        pivot = i;
-      }
-    }
-    if (j != pivot) {
-      for (int k = 0; k < m; ++k) std::swap(a[(size_t)pivot * m + k], a[(size_t)j * m + k]);
-      scale[pivot] = scale[j];
-    }
-    perm[j] = pivot;
-    if (a[(size_t)j * m + j] == 0.0) a[(size_t)j * m + j] = DBL_EPSILON;
-    if (j != m - 1) {
-      const double t = 1.0 / a[(size_t)j * m + j];
-      for (int i = j + 1; i < m; ++i) a[(size_t)i * m + j] *= t;
-    }
+    float temp = eps * fabsf(p[j]);
+    if (temp == 0.0f) temp = eps;
+    pp[j] = p[j] + temp;
   }
-  int first = 0;
-  for (int i = 0; i < m; ++i) {
-    const int ip = perm[i];
-    double s = x[ip];
-    x[ip] = x[i];
-    if (first != 0) {
-      for (int jj = first - 1; jj < i; ++jj) s -= a[(size_t)i * m + jj] * x[jj];
-    } else if (s != 0.0) {
-      first = i + 1;
-    }
-    x[i] = s;
-  }
-  for (int i = m - 1; i >= 0; --i) {
-    double s = x[i];
-    for (int j = i + 1; j < m; ++j) s -= a[(size_t)i * m + j] * x[j];
-    x[i] = s / a[(size_t)i * m + i];
-  }
-  return 1;
+  (*func)(pp.data(), fvecp.data(), m, n, adata);
+  (void)chkjac_err_run_f(fvec.data(), fjac.data(), fvecp.data(), p, m, n, err);
 }
 
 int brdf_hip_register_model(void (*func)(double *, double *, int, int, void *)) {

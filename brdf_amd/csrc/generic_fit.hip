@@ -30,40 +30,42 @@ constexpr int kGenSums = kGenMaxM * (kGenMaxM + 1) / 2 + kGenMaxM + 2;  // JtJ l
 constexpr int kGenThreads = 256;
 constexpr int kGenExactLimit = 65536;
 
+template <class Real>
 struct GenArgs {
-  const double *x;    // measurements (zeros if the caller passed NULL)
-  const double *hx;   // f(p)                       (device copy kept across passes for dif)
-  const double *aux;  // RQ_EVAL: f(point); RQ_JAC/RQ_DIF_JAC: hxx planes [j][n] (central: [2j] minus, [2j+1] plus)
-  double *wrk;        // dif: f(p + Dp) of the last trial
-  double *hx_rw;      // writable alias of hx (accept: hx <- wrk)
-  double *jac;        // n x m row-major, as levmar stores it (jac[i*m + j])
-  double *out;        // kGenSums doubles
+  const Real *x;    // measurements (zeros if the caller passed NULL)
+  const Real *hx;   // f(p)                       (device copy kept across passes for dif)
+  const Real *aux;  // RQ_EVAL: f(point); RQ_JAC/RQ_DIF_JAC: hxx planes [j][n] (central: [2j] minus, [2j+1] plus)
+  Real *wrk;        // dif: f(p + Dp) of the last trial
+  Real *hx_rw;      // writable alias of hx (accept: hx <- wrk)
+  Real *jac;        // n x m row-major, as levmar stores it (jac[i*m + j])
+  Real *out;        // kGenSums doubles
   int n, m, kind, central, exact, accepted, bc_rule, store_hx, user_jac;
-  double dinv[kGenMaxM], dp[kGenMaxM], dp_l2, scal;
+  Real dinv[kGenMaxM], dp[kGenMaxM], dp_l2, scal;
 };
 
 // ---- exact (reference-order) single-lane routines ---------------------------------------------------------
-__device__ double ref_l2(const double *x, const double *y, int n, double scal, bool scaled, double *mx_out) {
-  double acc[4] = {0.0, 0.0, 0.0, 0.0};
-  double mx = 0.0;
+template <class Real>
+__device__ Real ref_l2(const Real *x, const Real *y, int n, Real scal, bool scaled, Real *mx_out) {
+  Real acc[4] = {Real(0.0), Real(0.0), Real(0.0), Real(0.0)};
+  Real mx = Real(0.0);
   if (scaled) {  // lmbc_core.c:163-166, descending
-    double s = 0.0;
+    Real s = Real(0.0);
     for (int i = n; i-- > 0;) {
-      const double t = (x[i] - y[i]) / scal;
+      const Real t = (x[i] - y[i]) / scal;
       s += t * t;
     }
-    *mx_out = 0.0;
+    *mx_out = Real(0.0);
     return s;
   }
   const int body = (n >> 3) << 3;  // misc_core.c:732-768
   for (int top = body - 1; top > 0; top -= 8)
     for (int k = 0; k < 8; ++k) {
-      const double e = x[top - k] - y[top - k];
+      const Real e = x[top - k] - y[top - k];
       acc[k & 3] += e * e;
       mx = fmax(mx, fabs(e));
     }
   for (int t = body; t < n; ++t) {
-    const double e = x[t] - y[t];
+    const Real e = x[t] - y[t];
     acc[(7 - (n - t)) & 3] += e * e;
     mx = fmax(mx, fabs(e));
   }
@@ -71,52 +73,55 @@ __device__ double ref_l2(const double *x, const double *y, int n, double scal, b
   return acc[0] + acc[1] + acc[2] + acc[3];
 }
 
-__device__ void ref_jtj_jte(const double *jac, const double *x, const double *h, int n, int m, bool small, double *jtj /*m*m*/,
-                            double *jte) {
+template <class Real>
+__device__ void ref_jtj_jte(const Real *jac, const Real *x, const Real *h, int n, int m, bool small, Real *jtj /*m*m*/,
+                            Real *jte) {
   if (small) {  // lm_core.c:617-637 / lmbc_core.c:595-615
-    for (int i = m * m; i-- > 0;) jtj[i] = 0.0;
-    for (int i = m; i-- > 0;) jte[i] = 0.0;
+    for (int i = m * m; i-- > 0;) jtj[i] = Real(0.0);
+    for (int i = m; i-- > 0;) jte[i] = Real(0.0);
     for (int l = n; l-- > 0;) {
-      const double *row = jac + (size_t)l * m;
-      const double el = x[l] - h[l];
+      const Real *row = jac + (size_t)l * m;
+      const Real el = x[l] - h[l];
       for (int i = m; i-- > 0;) {
-        const double alpha = row[i];
+        const Real alpha = row[i];
         for (int j = i + 1; j-- > 0;) jtj[i * m + j] += row[j] * alpha;
         jte[i] += alpha * el;
       }
     }
   } else {  // misc_core.c:103-128 (32-row blocks, upper triangle) + lm_core.c:645-653
     for (int i = 0; i < m; ++i)
-      for (int j = i; j < m; ++j) jtj[i * m + j] = 0.0;
+      for (int j = i; j < m; ++j) jtj[i * m + j] = Real(0.0);
     for (int kk = 0; kk < n; kk += 32) {
       const int kend = (kk + 32 <= n) ? kk + 32 : n;
       for (int i = 0; i < m; ++i)
         for (int j = i; j < m; ++j) {
-          double s = 0.0;
+          Real s = Real(0.0);
           for (int k = kk; k < kend; ++k) s += jac[(size_t)k * m + i] * jac[(size_t)k * m + j];
           jtj[i * m + j] += s;
         }
     }
     for (int i = 0; i < m; ++i)
       for (int j = 0; j < i; ++j) jtj[i * m + j] = jtj[j * m + i];
-    for (int i = 0; i < m; ++i) jte[i] = 0.0;
+    for (int i = 0; i < m; ++i) jte[i] = Real(0.0);
     for (int i = 0; i < n; ++i) {
-      const double ei = x[i] - h[i];
+      const Real ei = x[i] - h[i];
       for (int l = 0; l < m; ++l) jte[l] += jac[(size_t)i * m + l] * ei;
     }
   }
 }
 
-__device__ void pack_sums(const double *jtj, const double *jte, int m, double *out) {
+template <class Real>
+__device__ void pack_sums(const Real *jtj, const Real *jte, int m, Real *out) {
   int c = 0;
   for (int i = 0; i < m; ++i)
     for (int j = 0; j <= i; ++j) out[c++] = jtj[i * m + j];
   for (int i = 0; i < m; ++i) out[c++] = jte[i];
 }
 
-__global__ __launch_bounds__(kGenThreads) void gen_pass_kernel(GenArgs a) {
-  __shared__ double part[kGenThreads];
-  __shared__ double sh_out[kGenSums];
+template <class Real>
+__global__ __launch_bounds__(kGenThreads) void gen_pass_kernel(GenArgs<Real> a) {
+  __shared__ Real part[kGenThreads];
+  __shared__ Real sh_out[kGenSums];
   const int tid = threadIdx.x;
   const int n = a.n, m = a.m;
   const int nl = m * (m + 1) / 2;
@@ -129,14 +134,14 @@ __global__ __launch_bounds__(kGenThreads) void gen_pass_kernel(GenArgs a) {
   } else if ((a.kind == RQ_JAC || a.kind == RQ_DIF_JAC) && !a.user_jac) {  // misc_core.c:167-170 / :206-209
     for (int i = tid; i < n; i += kGenThreads)
       for (int j = 0; j < m; ++j) {
-        const double v = a.central ? (a.aux[(size_t)(2 * j + 1) * n + i] - a.aux[(size_t)(2 * j) * n + i])
+        const Real v = a.central ? (a.aux[(size_t)(2 * j + 1) * n + i] - a.aux[(size_t)(2 * j) * n + i])
                                    : (a.aux[(size_t)j * n + i] - a.hx[i]);
         a.jac[(size_t)i * m + j] = v * a.dinv[j];
       }
   } else if (a.kind == RQ_DIF_UPDATE) {  // lm_core.c:760-766
     for (int i = tid; i < n; i += kGenThreads) {
-      double *row = a.jac + (size_t)i * m;
-      double t = 0.0;
+      Real *row = a.jac + (size_t)i * m;
+      Real t = Real(0.0);
       for (int l = 0; l < m; ++l) t += row[l] * a.dp[l];
       t = (a.wrk[i] - a.hx[i] - t) / a.dp_l2;
       for (int j = 0; j < m; ++j) row[j] += t * a.dp[j];
@@ -144,21 +149,21 @@ __global__ __launch_bounds__(kGenThreads) void gen_pass_kernel(GenArgs a) {
   }
   __syncthreads();
 
-  const double *y = (a.kind == RQ_EVAL || a.kind == RQ_SCALED) ? a.aux : ((a.kind == RQ_DIF_TRIAL) ? a.wrk : a.hx);
-  const double *h_for_e = (a.kind == RQ_DIF_UPDATE && a.accepted) ? a.wrk : a.hx;  // residual paired with J^T e
+  const Real *y = (a.kind == RQ_EVAL || a.kind == RQ_SCALED) ? a.aux : ((a.kind == RQ_DIF_TRIAL) ? a.wrk : a.hx);
+  const Real *h_for_e = (a.kind == RQ_DIF_UPDATE && a.accepted) ? a.wrk : a.hx;  // residual paired with J^T e
   const bool wants_norm = (a.kind == RQ_EVAL || a.kind == RQ_SCALED || a.kind == RQ_DIF_INIT || a.kind == RQ_DIF_TRIAL || a.kind == RQ_JAC);
   const bool wants_jtj = (a.kind == RQ_JAC || a.kind == RQ_DIF_JAC || a.kind == RQ_DIF_UPDATE);
 
   if (a.exact) {
     if (tid == 0) {
-      double mx = 0.0;
+      Real mx = Real(0.0);
       if (wants_jtj) {
-        double jtj[kGenMaxM * kGenMaxM], jte[kGenMaxM];
+        Real jtj[kGenMaxM * kGenMaxM], jte[kGenMaxM];
         const int nm = n * m;
         const bool small = a.bc_rule ? (nm < 1024) : (nm <= 1024);
         ref_jtj_jte(a.jac, a.x, h_for_e, n, m, small, jtj, jte);
         pack_sums(jtj, jte, m, sh_out);
-        if (a.kind == RQ_JAC) sh_out[nl + m] = ref_l2(a.x, a.hx, n, 1.0, false, &mx);
+        if (a.kind == RQ_JAC) sh_out[nl + m] = ref_l2(a.x, a.hx, n, Real(1.0), false, &mx);
       } else if (wants_norm) {
         sh_out[0] = ref_l2(a.x, y, n, a.scal, a.kind == RQ_SCALED, &mx);
       }
@@ -168,23 +173,23 @@ __global__ __launch_bounds__(kGenThreads) void gen_pass_kernel(GenArgs a) {
   } else {
     // deterministic tree: strided per-lane accumulation, then a fixed LDS fold per sum
     const int nsum = wants_jtj ? (nl + m + (a.kind == RQ_JAC ? 1 : 0)) : 1;
-    double acc[kGenSums];
-    for (int k = 0; k < kGenSums; ++k) acc[k] = 0.0;
-    double mx = 0.0;
+    Real acc[kGenSums];
+    for (int k = 0; k < kGenSums; ++k) acc[k] = Real(0.0);
+    Real mx = Real(0.0);
     for (int i = tid; i < n; i += kGenThreads) {
       if (wants_jtj) {
-        const double *row = a.jac + (size_t)i * m;
-        const double e = a.x[i] - h_for_e[i];
+        const Real *row = a.jac + (size_t)i * m;
+        const Real e = a.x[i] - h_for_e[i];
         int c = 0;
         for (int r = 0; r < m; ++r)
           for (int j = 0; j <= r; ++j) acc[c++] += row[r] * row[j];
         for (int r = 0; r < m; ++r) acc[c++] += row[r] * e;
         if (a.kind == RQ_JAC) {
-          const double e0 = a.x[i] - a.hx[i];
+          const Real e0 = a.x[i] - a.hx[i];
           acc[c] += e0 * e0;
         }
       } else {
-        double e = a.x[i] - y[i];
+        Real e = a.x[i] - y[i];
         if (a.kind == RQ_SCALED) e /= a.scal;
         acc[0] += e * e;
         mx = fmax(mx, fabs(e));
@@ -194,7 +199,7 @@ __global__ __launch_bounds__(kGenThreads) void gen_pass_kernel(GenArgs a) {
       part[tid] = (k < nsum) ? acc[k] : mx;
       __syncthreads();
       if (tid == 0) {
-        double s = part[0];
+        Real s = part[0];
         if (k < nsum)
           for (int t = 1; t < kGenThreads; ++t) s += part[t];
         else
@@ -222,25 +227,30 @@ __global__ __launch_bounds__(kGenThreads) void gen_pass_kernel(GenArgs a) {
     }                                                                                 \
   } while (0)
 
-typedef void (*user_func_t)(double *p, double *hx, int m, int n, void *adata);
-typedef void (*user_jacf_t)(double *p, double *jac, int m, int n, void *adata);
+template <class Real>
+using user_func_of = void (*)(Real *p, Real *hx, int m, int n, void *adata);
+template <class Real>
+using user_jacf_of = void (*)(Real *p, Real *jac, int m, int n, void *adata);
+typedef user_func_of<double> user_func_t;
+typedef user_jacf_of<double> user_jacf_t;
 
 namespace {
 
+template <class Real>
 struct GenBuffers {
-  double *d = nullptr;
+  Real *d = nullptr;
   size_t cap = 0;
   ~GenBuffers() {
     if (d) (void)hipFree(d);
   }
 };
 
-template <int M, int METHOD>
-int generic_run(user_func_t func, user_jacf_t jacf, double *p, double *x, int n, double *lb, double *ub, double *dscl, int itmax,
-                double *opts, double *info, double *covar, void *adata) {
+template <int M, int METHOD, class Real>
+int generic_run(user_func_of<Real> func, user_jacf_of<Real> jacf, Real *p, Real *x, int n, Real *lb, Real *ub, Real *dscl, int itmax,
+                Real *opts, Real *info, Real *covar, void *adata) {
   // METHOD: 0 dlevmar_dif, 1 dlevmar_bc_dif / dlevmar_bc_der, 2 dlevmar_der
-  using Machine = typename std::conditional<METHOD == 0, DifMachine<M>,
-                                            typename std::conditional<METHOD == 1, BcMachine<M>, DerMachine<M>>::type>::type;
+  using Machine = typename std::conditional<METHOD == 0, DifMachine<M, Real>,
+                                            typename std::conditional<METHOD == 1, BcMachine<M, Real>, DerMachine<M, Real>>::type>::type;
   Machine mach;
   if constexpr (METHOD == 0)
     mach.start(p, n, itmax, opts, covar != nullptr, /*speculative=*/0);
@@ -260,8 +270,8 @@ int generic_run(user_func_t func, user_jacf_t jacf, double *p, double *x, int n,
         return kLmError;
       }
     }
-    set_error("%s(): cannot solve a problem with fewer measurements [%d] than unknowns [%d]",
-              METHOD == 0 ? "dlevmar_dif" : (METHOD == 1 ? "dlevmar_bc_dif" : "dlevmar_der"), n, M);
+    set_error("%clevmar_%s(): cannot solve a problem with fewer measurements [%d] than unknowns [%d]", sizeof(Real) == 4 ? 's' : 'd',
+              METHOD == 0 ? "dif" : (METHOD == 1 ? "bc_dif" : "der"), n, M);
     return kLmError;
   }
   if constexpr (METHOD == 1)
@@ -272,18 +282,18 @@ int generic_run(user_func_t func, user_jacf_t jacf, double *p, double *x, int n,
 
   // device buffers: x | hx | wrk | aux (2M planes) | jac (n*M) | out
   const size_t need = (size_t)n * (3 + 2 * M + M) + kGenSums;
-  GenBuffers buf;
-  HIP_OK(hipMalloc(&buf.d, need * sizeof(double)));
-  double *d_x = buf.d, *d_hx = d_x + n, *d_wrk = d_hx + n, *d_aux = d_wrk + n, *d_jac = d_aux + (size_t)2 * M * n,
+  GenBuffers<Real> buf;
+  HIP_OK(hipMalloc(&buf.d, need * sizeof(Real)));
+  Real *d_x = buf.d, *d_hx = d_x + n, *d_wrk = d_hx + n, *d_aux = d_wrk + n, *d_jac = d_aux + (size_t)2 * M * n,
          *d_out = d_jac + (size_t)n * M;
-  std::vector<double> host_aux((size_t)2 * M * n);
+  std::vector<Real> host_aux((size_t)2 * M * n);
   if (x) {
-    HIP_OK(hipMemcpy(d_x, x, sizeof(double) * n, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(d_x, x, sizeof(Real) * n, hipMemcpyHostToDevice));
   } else {  // "NULL implies a zero vector", lm_core.c:441
-    HIP_OK(hipMemset(d_x, 0, sizeof(double) * n));
+    HIP_OK(hipMemset(d_x, 0, sizeof(Real) * n));
   }
-  double sums_host[kGenSums];
-  double sums[SumLayout<M>::MAX + 2];
+  Real sums_host[kGenSums];
+  Real sums[SumLayout<M>::MAX + 2];
   const bool exact = (long long)n * M <= kGenExactLimit;
 
   long long guard = 0;
@@ -293,8 +303,8 @@ int generic_run(user_func_t func, user_jacf_t jacf, double *p, double *x, int n,
       set_error("pass budget exhausted without termination");
       return kLmError;
     }
-    const Request<M> &r = mach.h.req;
-    GenArgs a;
+    const Request<M, Real> &r = mach.h.req;
+    GenArgs<Real> a;
     memset(&a, 0, sizeof a);
     a.x = d_x;
     a.hx = d_hx;
@@ -313,7 +323,7 @@ int generic_run(user_func_t func, user_jacf_t jacf, double *p, double *x, int n,
     a.scal = r.scal;
     a.dp_l2 = r.dp_l2;
     for (int j = 0; j < M; ++j) a.dp[j] = r.dp[j];
-    double pt[M];
+    Real pt[M];
     size_t planes = 0;
     switch (r.kind) {
     case RQ_EVAL:
@@ -331,13 +341,13 @@ int generic_run(user_func_t func, user_jacf_t jacf, double *p, double *x, int n,
     case RQ_JAC:
       if (jacf) {  // dlevmar_bc_der: the caller's analytic Jacobian (lmbc_core.c:555-557).  The residual paired with
                    // J^T e is x - f(p) of the accepted point; f is deterministic, so it is simply evaluated again here
-        std::vector<double> jh((size_t)n * M);
+        std::vector<Real> jh((size_t)n * M);
         for (int j = 0; j < M; ++j) pt[j] = r.p[j];
         func(pt, host_aux.data(), M, n, adata);
-        HIP_OK(hipMemcpy(d_hx, host_aux.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(d_hx, host_aux.data(), sizeof(Real) * n, hipMemcpyHostToDevice));
         for (int j = 0; j < M; ++j) pt[j] = r.p[j];
         jacf(pt, jh.data(), M, n, adata);
-        HIP_OK(hipMemcpy(d_jac, jh.data(), sizeof(double) * (size_t)n * M, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(d_jac, jh.data(), sizeof(Real) * (size_t)n * M, hipMemcpyHostToDevice));
         a.user_jac = 1;
         break;
       }
@@ -345,12 +355,12 @@ int generic_run(user_func_t func, user_jacf_t jacf, double *p, double *x, int n,
       if (!r.central) {
         for (int j = 0; j < M; ++j) pt[j] = r.p[j];
         func(pt, host_aux.data() + (size_t)M * n, M, n, adata);  // parked behind the M difference planes
-        HIP_OK(hipMemcpy(d_hx, host_aux.data() + (size_t)M * n, sizeof(double) * n, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(d_hx, host_aux.data() + (size_t)M * n, sizeof(Real) * n, hipMemcpyHostToDevice));
       }
       [[fallthrough]];
     case RQ_DIF_JAC:
       for (int j = 0; j < M; ++j) {
-        a.dinv[j] = (r.central ? 0.5 : 1.0) / r.d[j];
+        a.dinv[j] = (r.central ? Real(0.5) : Real(1.0)) / r.d[j];
         for (int k = 0; k < M; ++k) pt[k] = r.p[k];
         if (!r.central) {
           pt[j] = r.p[j] + r.d[j];
@@ -366,13 +376,13 @@ int generic_run(user_func_t func, user_jacf_t jacf, double *p, double *x, int n,
       break;
     default: break;  // RQ_DIF_UPDATE: no evaluation
     }
-    if (planes) HIP_OK(hipMemcpy(d_aux, host_aux.data(), sizeof(double) * planes * n, hipMemcpyHostToDevice));
+    if (planes) HIP_OK(hipMemcpy(d_aux, host_aux.data(), sizeof(Real) * planes * n, hipMemcpyHostToDevice));
     // (bc with central differences never evaluates f(p): the residual paired with J^T e is the one of the last
     // accepted point, which the device keeps in hx -- refreshed below whenever an evaluation is accepted)
     a.store_hx = 0;
-    hipLaunchKernelGGL(gen_pass_kernel, dim3(1), dim3(kGenThreads), 0, 0, a);
+    hipLaunchKernelGGL(gen_pass_kernel<Real>, dim3(1), dim3(kGenThreads), 0, 0, a);
     HIP_OK(hipGetLastError());
-    HIP_OK(hipMemcpy(sums_host, d_out, sizeof(double) * kGenSums, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(sums_host, d_out, sizeof(Real) * kGenSums, hipMemcpyDeviceToHost));
     const int ns = (r.kind == RQ_JAC) ? SumLayout<M>::JAC : ((r.kind == RQ_DIF_JAC || r.kind == RQ_DIF_UPDATE) ? SumLayout<M>::DIF_JAC : 1);
     for (int k = 0; k < ns; ++k) sums[k] = sums_host[k];
     const int kind_done = r.kind;
@@ -383,10 +393,10 @@ int generic_run(user_func_t func, user_jacf_t jacf, double *p, double *x, int n,
       // that was just evaluated.
       bool same = true;
       for (int j = 0; j < M; ++j) {
-        const double cur = mach.c.has_dscl ? mach.h.p[j] * mach.c.dscl[j] : mach.h.p[j];
+        const Real cur = mach.c.has_dscl ? mach.h.p[j] * mach.c.dscl[j] : mach.h.p[j];
         if (cur != pt[j]) same = false;
       }
-      if (same) HIP_OK(hipMemcpy(d_hx, d_aux, sizeof(double) * n, hipMemcpyDeviceToDevice));
+      if (same) HIP_OK(hipMemcpy(d_hx, d_aux, sizeof(Real) * n, hipMemcpyDeviceToDevice));
     }
   }
   for (int i = 0; i < M; ++i) p[i] = mach.h.p[i];
@@ -397,18 +407,18 @@ int generic_run(user_func_t func, user_jacf_t jacf, double *p, double *x, int n,
   return mach.c.ret;
 }
 
-template <int METHOD>
-int generic_dispatch(user_func_t func, user_jacf_t jacf, double *p, double *x, int m, int n, double *lb, double *ub, double *dscl, int itmax,
-                     double *opts, double *info, double *covar, void *adata) {
+template <int METHOD, class Real>
+int generic_dispatch(user_func_of<Real> func, user_jacf_of<Real> jacf, Real *p, Real *x, int m, int n, Real *lb, Real *ub, Real *dscl, int itmax,
+                     Real *opts, Real *info, Real *covar, void *adata) {
   switch (m) {
-  case 1: return generic_run<1, METHOD>(func, jacf, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
-  case 2: return generic_run<2, METHOD>(func, jacf, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
-  case 3: return generic_run<3, METHOD>(func, jacf, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
-  case 4: return generic_run<4, METHOD>(func, jacf, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
-  case 5: return generic_run<5, METHOD>(func, jacf, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
-  case 6: return generic_run<6, METHOD>(func, jacf, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
-  case 7: return generic_run<7, METHOD>(func, jacf, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
-  case 8: return generic_run<8, METHOD>(func, jacf, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
+  case 1: return generic_run<1, METHOD, Real>(func, jacf, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
+  case 2: return generic_run<2, METHOD, Real>(func, jacf, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
+  case 3: return generic_run<3, METHOD, Real>(func, jacf, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
+  case 4: return generic_run<4, METHOD, Real>(func, jacf, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
+  case 5: return generic_run<5, METHOD, Real>(func, jacf, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
+  case 6: return generic_run<6, METHOD, Real>(func, jacf, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
+  case 7: return generic_run<7, METHOD, Real>(func, jacf, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
+  case 8: return generic_run<8, METHOD, Real>(func, jacf, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
   }
   set_error("generic callback path supports 1 <= m <= %d parameters (got %d)", kGenMaxM, m);
   return kLmError;
@@ -423,55 +433,70 @@ int generic_fit_run(int method, user_func_t func, user_jacf_t jacf, double *p, d
     return kLmError;
   }
   (void)hipGetLastError();
-  if (method == 0) return generic_dispatch<0>(func, nullptr, p, x, m, n, lb, ub, dscl, itmax, opts, info, covar, adata);
-  if (method == 2) return generic_dispatch<2>(func, jacf, p, x, m, n, nullptr, nullptr, nullptr, itmax, opts, info, covar, adata);
-  return generic_dispatch<1>(func, jacf, p, x, m, n, lb, ub, dscl, itmax, opts, info, covar, adata);
+  if (method == 0) return generic_dispatch<0, double>(func, nullptr, p, x, m, n, lb, ub, dscl, itmax, opts, info, covar, adata);
+  if (method == 2) return generic_dispatch<2, double>(func, jacf, p, x, m, n, nullptr, nullptr, nullptr, itmax, opts, info, covar, adata);
+  return generic_dispatch<1, double>(func, jacf, p, x, m, n, lb, ub, dscl, itmax, opts, info, covar, adata);
+}
+
+// the single-precision twins (slevmar_*, levmar.h:208-310): the same machines and kernels instantiated with Real = float
+int generic_fit_run_f(int method, user_func_of<float> func, user_jacf_of<float> jacf, float *p, float *x, int m, int n, float *lb,
+                      float *ub, float *dscl, int itmax, float *opts, float *info, float *covar, void *adata) {
+  if (!func || !p || n <= 0) {
+    set_error("generic fit: null callback / parameter vector or n <= 0");
+    return kLmError;
+  }
+  (void)hipGetLastError();
+  if (method == 0) return generic_dispatch<0, float>(func, nullptr, p, x, m, n, lb, ub, dscl, itmax, opts, info, covar, adata);
+  if (method == 2) return generic_dispatch<2, float>(func, jacf, p, x, m, n, nullptr, nullptr, nullptr, itmax, opts, info, covar, adata);
+  return generic_dispatch<1, float>(func, jacf, p, x, m, n, lb, ub, dscl, itmax, opts, info, covar, adata);
 }
 
 
 // dlevmar_chkjac's comparison of the n rows (misc_core.c:286-318), one row per lane
-__global__ __launch_bounds__(256) void chkjac_kernel(const double *__restrict__ fvec, const double *__restrict__ fjac,
-                                                     const double *__restrict__ fvecp, const double *__restrict__ pabs, int m, int n,
-                                                     double *__restrict__ err) {
-  const double epsmch = DBL_EPSILON, eps = sqrt(epsmch), epsf = 100.0 * epsmch, epslog = log10(eps);
+template <class Real>
+__global__ __launch_bounds__(256) void chkjac_kernel(const Real *__restrict__ fvec, const Real *__restrict__ fjac,
+                                                     const Real *__restrict__ fvecp, const Real *__restrict__ pabs, int m, int n,
+                                                     Real *__restrict__ err) {
+  const Real epsmch = LmLimits<Real>::eps(), eps = sqrt(epsmch), epsf = Real(100.0) * epsmch, epslog = log10(eps);
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    double e = 0.0;
+    Real e = Real(0.0);
     for (int j = 0; j < m; ++j) e += pabs[j] * fjac[(size_t)i * m + j];  // temp = |p[j]| (1 if zero), :290-296
-    double temp = 1.0;
-    const double f = fvec[i], fp = fvecp[i];
-    if (f != 0.0 && fp != 0.0 && fabs(fp - f) >= epsf * fabs(f)) temp = eps * fabs((fp - f) / eps - e) / (fabs(f) + fabs(fp));
-    double r = 1.0;
+    Real temp = Real(1.0);
+    const Real f = fvec[i], fp = fvecp[i];
+    if (f != Real(0.0) && fp != Real(0.0) && fabs(fp - f) >= epsf * fabs(f)) temp = eps * fabs((fp - f) / eps - e) / (fabs(f) + fabs(fp));
+    Real r = Real(1.0);
     if (temp > epsmch && temp < eps) r = (log10(temp) - epslog) / epslog;
-    if (temp >= eps) r = 0.0;
+    if (temp >= eps) r = Real(0.0);
     err[i] = r;
   }
 }
 
-int chkjac_err_run(const double *fvec, const double *fjac, const double *fvecp, const double *p, int m, int n, double *err) {
+template <class Real>
+int chkjac_err_run_t(const Real *fvec, const Real *fjac, const Real *fvecp, const Real *p, int m, int n, Real *err) {
   (void)hipGetLastError();
-  double *d = nullptr;
+  Real *d = nullptr;
   const size_t total = (size_t)n * (m + 3) + m;
-  if (hipMalloc(&d, total * sizeof(double)) != hipSuccess) {
+  if (hipMalloc(&d, total * sizeof(Real)) != hipSuccess) {
     set_error("dlevmar_chkjac(): hipMalloc failed");
     return kLmError;
   }
-  double *d_fvec = d, *d_fvecp = d + n, *d_err = d + 2 * (size_t)n, *d_p = d + 3 * (size_t)n, *d_fjac = d_p + m;
-  std::vector<double> pabs(m);
+  Real *d_fvec = d, *d_fvecp = d + n, *d_err = d + 2 * (size_t)n, *d_p = d + 3 * (size_t)n, *d_fjac = d_p + m;
+  std::vector<Real> pabs(m);
   for (int j = 0; j < m; ++j) {
     pabs[j] = fabs(p[j]);
-    if (pabs[j] == 0.0) pabs[j] = 1.0;
+    if (pabs[j] == Real(0.0)) pabs[j] = Real(1.0);
   }
-  hipError_t e = hipMemcpy(d_fvec, fvec, sizeof(double) * n, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(d_fvecp, fvecp, sizeof(double) * n, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(d_fjac, fjac, sizeof(double) * (size_t)n * m, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(d_p, pabs.data(), sizeof(double) * m, hipMemcpyHostToDevice);
+  hipError_t e = hipMemcpy(d_fvec, fvec, sizeof(Real) * n, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_fvecp, fvecp, sizeof(Real) * n, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_fjac, fjac, sizeof(Real) * (size_t)n * m, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_p, pabs.data(), sizeof(Real) * m, hipMemcpyHostToDevice);
   if (e == hipSuccess) {
     int blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(chkjac_kernel, dim3(blocks), dim3(256), 0, nullptr, d_fvec, d_fjac, d_fvecp, d_p, m, n, d_err);
+    hipLaunchKernelGGL(chkjac_kernel<Real>, dim3(blocks), dim3(256), 0, nullptr, d_fvec, d_fjac, d_fvecp, d_p, m, n, d_err);
     e = hipGetLastError();
   }
-  if (e == hipSuccess) e = hipMemcpy(err, d_err, sizeof(double) * n, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(err, d_err, sizeof(Real) * n, hipMemcpyDeviceToHost);
   (void)hipFree(d);
   if (e != hipSuccess) {
     set_error("dlevmar_chkjac(): %s", hipGetErrorString(e));
@@ -483,23 +508,24 @@ int chkjac_err_run(const double *fvec, const double *fjac, const double *fvecp, 
 
 // dlevmar_R2's three sums (misc_core.c:634-654): sum x, then SS_err and SS_tot, each walked from the top index down.
 // Small problems: one lane, the reference's order.  Large ones: per-lane strided partial sums folded by a fixed tree.
-__global__ __launch_bounds__(256) void r2_kernel(const double *__restrict__ x, const double *__restrict__ hx, int n, int exact,
-                                                 double *__restrict__ out) {
-  __shared__ double part[3][256];
+template <class Real>
+__global__ __launch_bounds__(256) void r2_kernel(const Real *__restrict__ x, const Real *__restrict__ hx, int n, int exact,
+                                                 Real *__restrict__ out) {
+  __shared__ Real part[3][256];
   const int tid = threadIdx.x;
   if (exact) {
     if (tid == 0) {
-      double sx = 0.0;
+      Real sx = Real(0.0);
       for (int i = n; i-- > 0;) sx += x[i];
-      const double xavg = sx / (double)n;
-      double sse = 0.0, sst = 0.0;
+      const Real xavg = sx / (Real)n;
+      Real sse = Real(0.0), sst = Real(0.0);
       for (int i = n; i-- > 0;) {
-        double t = x[i] - hx[i];
+        Real t = x[i] - hx[i];
         sse += t * t;
         t = x[i] - xavg;
         sst += t * t;
       }
-      out[0] = 1.0 - sse / sst;
+      out[0] = Real(1.0) - sse / sst;
     }
     return;
   }
@@ -510,14 +536,14 @@ __global__ __launch_bounds__(256) void r2_kernel(const double *__restrict__ x, c
       __syncthreads();
     }
   };
-  double sx = 0.0;
+  Real sx = Real(0.0);
   for (int i = tid; i < n; i += 256) sx += x[i];
   part[0][tid] = sx;
   fold(0);
-  const double xavg = part[0][0] / (double)n;
-  double sse = 0.0, sst = 0.0;
+  const Real xavg = part[0][0] / (Real)n;
+  Real sse = Real(0.0), sst = Real(0.0);
   for (int i = tid; i < n; i += 256) {
-    double t = x[i] - hx[i];
+    Real t = x[i] - hx[i];
     sse += t * t;
     t = x[i] - xavg;
     sst += t * t;
@@ -526,23 +552,24 @@ __global__ __launch_bounds__(256) void r2_kernel(const double *__restrict__ x, c
   part[2][tid] = sst;
   fold(1);
   fold(2);
-  if (tid == 0) out[0] = 1.0 - part[1][0] / part[2][0];
+  if (tid == 0) out[0] = Real(1.0) - part[1][0] / part[2][0];
 }
 
-int r2_run(const double *x, const double *hx, int n, double *r2) {
+template <class Real>
+int r2_run_t(const Real *x, const Real *hx, int n, Real *r2) {
   (void)hipGetLastError();
-  double *d = nullptr;
-  if (hipMalloc(&d, (2 * (size_t)n + 1) * sizeof(double)) != hipSuccess) {
+  Real *d = nullptr;
+  if (hipMalloc(&d, (2 * (size_t)n + 1) * sizeof(Real)) != hipSuccess) {
     set_error("dlevmar_R2(): hipMalloc failed");
     return kLmError;
   }
-  hipError_t e = x ? hipMemcpy(d, x, sizeof(double) * n, hipMemcpyHostToDevice) : hipMemset(d, 0, sizeof(double) * n);
-  if (e == hipSuccess) e = hipMemcpy(d + n, hx, sizeof(double) * n, hipMemcpyHostToDevice);
+  hipError_t e = x ? hipMemcpy(d, x, sizeof(Real) * n, hipMemcpyHostToDevice) : hipMemset(d, 0, sizeof(Real) * n);
+  if (e == hipSuccess) e = hipMemcpy(d + n, hx, sizeof(Real) * n, hipMemcpyHostToDevice);
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(r2_kernel, dim3(1), dim3(256), 0, nullptr, d, d + n, n, n <= kGenExactLimit ? 1 : 0, d + 2 * (size_t)n);
+    hipLaunchKernelGGL(r2_kernel<Real>, dim3(1), dim3(256), 0, nullptr, d, d + n, n, n <= kGenExactLimit ? 1 : 0, d + 2 * (size_t)n);
     e = hipGetLastError();
   }
-  if (e == hipSuccess) e = hipMemcpy(r2, d + 2 * (size_t)n, sizeof(double), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(r2, d + 2 * (size_t)n, sizeof(Real), hipMemcpyDeviceToHost);
   (void)hipFree(d);
   if (e != hipSuccess) {
     set_error("dlevmar_R2(): %s", hipGetErrorString(e));
@@ -550,5 +577,14 @@ int r2_run(const double *x, const double *hx, int n, double *r2) {
   }
   return 0;
 }
+
+int chkjac_err_run(const double *fvec, const double *fjac, const double *fvecp, const double *p, int m, int n, double *err) {
+  return chkjac_err_run_t<double>(fvec, fjac, fvecp, p, m, n, err);
+}
+int chkjac_err_run_f(const float *fvec, const float *fjac, const float *fvecp, const float *p, int m, int n, float *err) {
+  return chkjac_err_run_t<float>(fvec, fjac, fvecp, p, m, n, err);
+}
+int r2_run(const double *x, const double *hx, int n, double *r2) { return r2_run_t<double>(x, hx, n, r2); }
+int r2_run_f(const float *x, const float *hx, int n, float *r2) { return r2_run_t<float>(x, hx, n, r2); }
 
 }  // namespace brdf

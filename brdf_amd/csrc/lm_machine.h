@@ -76,22 +76,38 @@ enum ReqKind : int {
 
 constexpr int kMaxCand = 8;  // candidates per RQ_EVAL_MULTI
 
-template <int M>
+// Real: the arithmetic type of a machine -- double (dlevmar_*, every BRDF kernel) or float (the slevmar_* twins,
+// levmar.h:208-310, instantiated from the same source exactly as the reference instantiates its *_core.c files with
+// LM_REAL = float, lm.c:43-63).  Every floating literal below is written Real(x), the reference's LM_CNST(x).
+template <class Real>
+struct LmLimits;
+template <>
+struct LmLimits<double> {
+  static LM_HD double eps() { return DBL_EPSILON; }
+  static LM_HD double max() { return DBL_MAX; }
+};
+template <>
+struct LmLimits<float> {
+  static LM_HD float eps() { return FLT_EPSILON; }
+  static LM_HD float max() { return FLT_MAX; }
+};
+
+template <int M, class Real = double>
 struct Request {
   int kind;
   int central;  // RQ_JAC / RQ_DIF_JAC: 0 forward, 1 central differences
   int sel_hx;   // which of the two hx buffers holds f(current p)     (dif only)
   int sel_j;    // which of the two Jacobian buffers is current       (dif only)
   int aux;      // RQ_DIF_UPDATE: 1 if the trial step was accepted
-  double p[M];  // evaluation point / Jacobian base point
-  double d[M];  // finite-difference steps                            (misc_core.c:155-158)
-  double q[M];  // trial point p+Dp                                   (RQ_DIF_TRIAL)
-  double dp[M]; // Dp                                                 (RQ_DIF_TRIAL)
-  double dp_l2; // ||Dp||^2
-  double scal;  // RQ_SCALED divisor
+  Real p[M];  // evaluation point / Jacobian base point
+  Real d[M];  // finite-difference steps                            (misc_core.c:155-158)
+  Real q[M];  // trial point p+Dp                                   (RQ_DIF_TRIAL)
+  Real dp[M]; // Dp                                                 (RQ_DIF_TRIAL)
+  Real dp_l2; // ||Dp||^2
+  Real scal;  // RQ_SCALED divisor
   int nk;       // RQ_EVAL_MULTI: number of candidate points
   int pad_;
-  double pk[kMaxCand][M];
+  Real pk[kMaxCand][M];
 };
 
 template <int M>
@@ -117,17 +133,19 @@ LM_HD int lm_uniform(int v) {
 #endif
 }
 
-LM_HD double lm_abs(double v) { return (v >= 0.0) ? v : -v; }
-LM_HD bool lm_finite(double v) { return (v - v) == 0.0; }  // false for NaN and +-Inf
+template <class Real>
+LM_HD Real lm_abs(Real v) { return (v >= Real(0.0)) ? v : -v; }
+template <class Real>
+LM_HD bool lm_finite(Real v) { return (v - v) == Real(0.0); }  // false for NaN and +-Inf
 
 // Crout LU with implicit row scaling + partial pivoting and the DBL_EPSILON zero-pivot rule, then
 // forward/back substitution: Axb_core.c:1197-1270.  A, B untouched; returns 0 if a row of A is zero.
 // Every array index below is a compile-time constant after unrolling (row exchanges and the
 // permuted right-hand-side picks are written as selects over all candidate rows), so on the GPU the
 // factorisation lives entirely in registers -- no scratch memory, no indirect register access.
-template <int M>
-LM_HD int lu_solve(const double *A, const double *B, double *x) {
-  double a[M * M], scale[M];
+template <int M, class Real>
+LM_HD int lu_solve(const Real *A, const Real *B, Real *x) {
+  Real a[M * M], scale[M];
   int perm[M];
 #pragma unroll
   for (int i = 0; i < M * M; ++i) a[i] = A[i];
@@ -135,33 +153,33 @@ LM_HD int lu_solve(const double *A, const double *B, double *x) {
   for (int i = 0; i < M; ++i) x[i] = B[i];
 #pragma unroll
   for (int i = 0; i < M; ++i) {
-    double big = 0.0;
+    Real big = Real(0.0);
 #pragma unroll
     for (int j = 0; j < M; ++j) {
-      const double t = lm_abs(a[i * M + j]);
+      const Real t = lm_abs(a[i * M + j]);
       if (t > big) big = t;
     }
-    if (big == 0.0) return 0;
-    scale[i] = 1.0 / big;
+    if (big == Real(0.0)) return 0;
+    scale[i] = Real(1.0) / big;
   }
 #pragma unroll
   for (int j = 0; j < M; ++j) {
     int pivot = j;
-    double big = 0.0;
+    Real big = Real(0.0);
 #pragma unroll
     for (int i = 0; i < j; ++i) {
-      double s = a[i * M + j];
+      Real s = a[i * M + j];
 #pragma unroll
       for (int k = 0; k < i; ++k) s -= a[i * M + k] * a[k * M + j];
       a[i * M + j] = s;
     }
 #pragma unroll
     for (int i = j; i < M; ++i) {
-      double s = a[i * M + j];
+      Real s = a[i * M + j];
 #pragma unroll
       for (int k = 0; k < j; ++k) s -= a[i * M + k] * a[k * M + j];
       a[i * M + j] = s;
-      const double t = scale[i] * lm_abs(s);
+      const Real t = scale[i] * lm_abs(s);
       if (t >= big) {
         big = t;
         pivot = i;
@@ -173,7 +191,7 @@ LM_HD int lu_solve(const double *A, const double *B, double *x) {
       if (pivot == r) {
 #pragma unroll
         for (int k = 0; k < M; ++k) {
-          const double t = a[r * M + k];
+          const Real t = a[r * M + k];
           a[r * M + k] = a[j * M + k];
           a[j * M + k] = t;
         }
@@ -181,9 +199,9 @@ LM_HD int lu_solve(const double *A, const double *B, double *x) {
       }
     }
     perm[j] = pivot;
-    if (a[j * M + j] == 0.0) a[j * M + j] = DBL_EPSILON;
+    if (a[j * M + j] == Real(0.0)) a[j * M + j] = LmLimits<Real>::eps();
     if (j != M - 1) {
-      const double t = 1.0 / a[j * M + j];
+      const Real t = Real(1.0) / a[j * M + j];
 #pragma unroll
       for (int i = j + 1; i < M; ++i) a[i * M + j] *= t;
     }
@@ -192,7 +210,7 @@ LM_HD int lu_solve(const double *A, const double *B, double *x) {
 #pragma unroll
   for (int i = 0; i < M; ++i) {
     // s = x[perm[i]]; x[perm[i]] = x[i];   with perm[i] >= i
-    double s = x[i];
+    Real s = x[i];
 #pragma unroll
     for (int r = i + 1; r < M; ++r) {
       if (perm[i] == r) {
@@ -204,14 +222,14 @@ LM_HD int lu_solve(const double *A, const double *B, double *x) {
 #pragma unroll
       for (int jj = 0; jj < i; ++jj)
         if (jj >= first - 1) s -= a[i * M + jj] * x[jj];
-    } else if (s != 0.0) {
+    } else if (s != Real(0.0)) {
       first = i + 1;
     }
     x[i] = s;
   }
 #pragma unroll
   for (int i = M - 1; i >= 0; --i) {
-    double s = x[i];
+    Real s = x[i];
 #pragma unroll
     for (int j = i + 1; j < M; ++j) s -= a[i * M + j] * x[j];
     x[i] = s / a[i * M + i];
@@ -220,31 +238,31 @@ LM_HD int lu_solve(const double *A, const double *B, double *x) {
 }
 
 // covar = sumsq/(n-M) * inverse(JtJ) by the same LU, column by column: misc_core.c:426-591.
-template <int M>
-LM_HD int lu_covar(const double *JtJ, double *C, double sumsq, int n) {
+template <int M, class Real>
+LM_HD int lu_covar(const Real *JtJ, Real *C, Real sumsq, int n) {
   for (int l = 0; l < M; ++l) {
-    double rhs[M], col[M];
-    for (int i = 0; i < M; ++i) rhs[i] = (i == l) ? 1.0 : 0.0;
+    Real rhs[M], col[M];
+    for (int i = 0; i < M; ++i) rhs[i] = (i == l) ? Real(1.0) : Real(0.0);
     if (!lu_solve<M>(JtJ, rhs, col)) return 0;
     for (int i = 0; i < M; ++i) C[i * M + l] = col[i];
   }
-  const double fact = sumsq / (double)(n - M);
+  const Real fact = sumsq / (Real)(n - M);
   for (int i = 0; i < M * M; ++i) C[i] *= fact;
   return M;
 }
 
-template <int M>
-LM_HD void fd_steps(const double *p, double delta, double *d) {  // misc_core.c:155-158
+template <int M, class Real>
+LM_HD void fd_steps(const Real *p, Real delta, Real *d) {  // misc_core.c:155-158
   for (int j = 0; j < M; ++j) {
-    double s = 1E-04 * p[j];
+    Real s = Real(1E-04) * p[j];
     s = lm_abs(s);
     if (s < delta) s = delta;
     d[j] = s;
   }
 }
 
-template <int M>
-LM_HD void unpack_lower(const double *s, double *jtj) {
+template <int M, class Real>
+LM_HD void unpack_lower(const Real *s, Real *jtj) {
   int c = 0;
   for (int i = 0; i < M; ++i)
     for (int j = 0; j <= i; ++j, ++c) {
@@ -253,14 +271,16 @@ LM_HD void unpack_lower(const double *s, double *jtj) {
     }
 }
 
-struct FitOptions {
-  double tau, eps1, eps2, eps2sq, eps3, delta;
+template <class Real = double>
+struct FitOptionsT {
+  Real tau, eps1, eps2, eps2sq, eps3, delta;
   int forward;
 };
 
 // opts == NULL selects the defaults of levmar.h:98-100 (lm_core.c:507-526)
-LM_HD FitOptions make_options(const double *opts) {
-  FitOptions o;
+template <class Real>
+LM_HD FitOptionsT<Real> make_options(const Real *opts) {
+  FitOptionsT<Real> o;
   if (opts) {
     o.tau = opts[0];
     o.eps1 = opts[1];
@@ -269,15 +289,15 @@ LM_HD FitOptions make_options(const double *opts) {
     o.eps3 = opts[3];
     o.delta = opts[4];
   } else {
-    o.tau = kInitMu;
-    o.eps1 = kStopThresh;
-    o.eps2 = kStopThresh;
-    o.eps2sq = kStopThresh * kStopThresh;
-    o.eps3 = kStopThresh;
-    o.delta = kDiffDelta;
+    o.tau = Real(kInitMu);
+    o.eps1 = Real(kStopThresh);
+    o.eps2 = Real(kStopThresh);
+    o.eps2sq = Real(kStopThresh) * Real(kStopThresh);
+    o.eps3 = Real(kStopThresh);
+    o.delta = Real(kDiffDelta);
   }
   o.forward = 1;
-  if (o.delta < 0.0) {
+  if (o.delta < Real(0.0)) {
     o.delta = -o.delta;
     o.forward = 0;
   }
@@ -290,14 +310,14 @@ LM_HD FitOptions make_options(const double *opts) {
 // Jacobian are produced speculatively by the trial pass (RQ_DIF_TRIAL) so that one pass per LM
 // iteration suffices; the machine decides afterwards which of the speculative results are live.
 // =================================================================================================
-template <int M>
+template <int M, class Real = double>
 struct DifMachine {
   enum Phase : int { D_INIT_EVAL = 1, D_ITER_TOP, D_AFTER_JAC, D_GRADIENT, D_SOLVE, D_AFTER_TRIAL, D_AFTER_UPDATE, D_DECIDE, D_REJECT, D_FINISH, D_DONE };
   // Cold: configuration and results, touched at start/finish only.  Hot: everything an LM step reads or
   // writes.  (Measured on gfx950: running the step on a register copy of Hot makes hipcc spill to scratch
   // and is slower than stepping in place in LDS, so step() works in place.)
   struct Cold {
-    FitOptions o;
+    FitOptionsT<Real> o;
     int itmax, n, want_covar, refresh;
     int speculative;  // 1: the trial pass also produces the products of the Broyden-updated Jacobian (one pass per LM
                       //    iteration).  The launch chain double-buffers J in HBM and commits by flipping sel_j; the
@@ -306,25 +326,25 @@ struct DifMachine {
                       // 0: trial pass, decision, then an update pass (RQ_DIF_UPDATE), the plain restatement of
                       //    lm_core.c:742-790: the host-callback path (generic_fit.hip), where hx and J are whole
                       //    vectors in HBM, and the host harness (tests/cpp/host_machine.cpp; bit-exact, like 1)
-    double info[kInfoSz], covar[M * M];
+    Real info[kInfoSz], covar[M * M];
     int ret;
   };
   struct Core {  // everything an LM step reads or writes, except the request it leaves
     int phase, k, stop, nu, nfev, njap, nlss, updjac, updp, newjac;
     int sel_hx, sel_j, accepted;
-    double p[M], mu, p_e2, jte_inf, p_l2, dp_l2, pdp_e2;
-    double jtj[M * M], jte[M], dp[M];
+    Real p[M], mu, p_e2, jte_inf, p_l2, dp_l2, pdp_e2;
+    Real jtj[M * M], jte[M], dp[M];
   };
   struct Cool {  // the less busy half of the state (see Hot)
-    double init_e2, diag[M], pdp[M];
-    double spec_jtj[M * M], spec_jte[M];  // normal equations of the Broyden-updated J, adopted lazily
+    Real init_e2, diag[M], pdp[M];
+    Real spec_jtj[M * M], spec_jte[M];  // normal equations of the Broyden-updated J, adopted lazily
   };
   // Core + Cool + the request.  run() takes them separately, so that a kernel can step on a REGISTER copy of Core
   // while the rest stays in LDS (resident_fit.hip: the sweeping waves read the request there; with Cool in registers as
   // well, hipcc spilled ~100 VGPRs of the step to scratch, which cost more than the LDS round trips it saved)
   struct Hot : Core {
     Cool cool;
-    Request<M> req;
+    Request<M, Real> req;
   };
   // where ONE machine is stepped by a whole wave (every lane the same values): moves the counters and flags of a
   // register copy into scalar registers, so that the step's integer logic and branches run on the scalar unit
@@ -346,8 +366,8 @@ struct DifMachine {
   Cold c;
   Hot h;
 
-  LM_HD void start(const double *p0, int n_, int itmax_, const double *opts, int want_covar_, int speculative_ = 1) {
-    Request<M> &req = h.req;
+  LM_HD void start(const Real *p0, int n_, int itmax_, const Real *opts, int want_covar_, int speculative_ = 1) {
+    Request<M, Real> &req = h.req;
     Cool &cool = h.cool;
     c.o = make_options(opts);
     c.speculative = speculative_;
@@ -363,17 +383,17 @@ struct DifMachine {
     h.newjac = 0;
     c.refresh = (M >= 10) ? M : 10;  // "K", lm_core.c:495
     h.sel_hx = h.sel_j = 0;
-    h.mu = h.jte_inf = h.p_l2 = 0.0;
-    h.p_e2 = cool.init_e2 = h.pdp_e2 = 0.0;
-    h.dp_l2 = DBL_MAX;
+    h.mu = h.jte_inf = h.p_l2 = Real(0.0);
+    h.p_e2 = cool.init_e2 = h.pdp_e2 = Real(0.0);
+    h.dp_l2 = LmLimits<Real>::max();
     c.ret = kLmError;
     for (int i = 0; i < M; ++i) {
       h.p[i] = p0[i];
-      h.jte[i] = cool.diag[i] = h.dp[i] = cool.pdp[i] = 0.0;
-      cool.spec_jte[i] = 0.0;
+      h.jte[i] = cool.diag[i] = h.dp[i] = cool.pdp[i] = Real(0.0);
+      cool.spec_jte[i] = Real(0.0);
     }
-    for (int i = 0; i < M * M; ++i) h.jtj[i] = cool.spec_jtj[i] = c.covar[i] = 0.0;
-    for (int i = 0; i < kInfoSz; ++i) c.info[i] = 0.0;
+    for (int i = 0; i < M * M; ++i) h.jtj[i] = cool.spec_jtj[i] = c.covar[i] = Real(0.0);
+    for (int i = 0; i < kInfoSz; ++i) c.info[i] = Real(0.0);
     clear_req(h, req);
     if (c.n < M) {  // lm_core.c:502-505
       h.phase = D_DONE;
@@ -385,21 +405,21 @@ struct DifMachine {
     h.phase = D_INIT_EVAL;
   }
 
-  static LM_HD void clear_req(const Core &h, Request<M> &req) {
+  static LM_HD void clear_req(const Core &h, Request<M, Real> &req) {
     req.kind = RQ_DONE;
     req.central = 0;
     req.sel_hx = h.sel_hx;
     req.sel_j = h.sel_j;
     req.aux = 0;
-    req.dp_l2 = 0.0;
-    req.scal = 1.0;
-    for (int i = 0; i < M; ++i) req.p[i] = req.d[i] = req.q[i] = req.dp[i] = 0.0;
+    req.dp_l2 = Real(0.0);
+    req.scal = Real(1.0);
+    for (int i = 0; i < M; ++i) req.p[i] = req.d[i] = req.q[i] = req.dp[i] = Real(0.0);
   }
 
   static LM_HD void gradient_stats(Core &h, Cool &cool) {  // lm_core.c:657-662
-    h.p_l2 = h.jte_inf = 0.0;
+    h.p_l2 = h.jte_inf = Real(0.0);
     for (int i = 0; i < M; ++i) {
-      const double t = lm_abs(h.jte[i]);
+      const Real t = lm_abs(h.jte[i]);
       if (h.jte_inf < t) h.jte_inf = t;
       cool.diag[i] = h.jtj[i * M + i];
       h.p_l2 += h.p[i] * h.p[i];
@@ -408,10 +428,10 @@ struct DifMachine {
 
   // ONE_LANE: the caller guarantees that exactly one lane of the wave executes this step (see lm_uniform)
   template <bool ONE_LANE = false>
-  LM_HD void step(const double *s, double maxabs) { run<ONE_LANE>(c, h, h.cool, h.req, s, maxabs); }
+  LM_HD void step(const Real *s, Real maxabs) { run<ONE_LANE>(c, h, h.cool, h.req, s, maxabs); }
 
   template <bool ONE_LANE>
-  static LM_HD void run(Cold &c, Core &h, Cool &cool, Request<M> &req, const double *s, double /*maxabs*/) {
+  static LM_HD void run(Cold &c, Core &h, Cool &cool, Request<M, Real> &req, const Real *s, Real /*maxabs*/) {
     int ph = ONE_LANE ? lm_uniform(h.phase) : h.phase;  // scalar register: phase transitions become scalar jumps
     LM_STAMP(0);
     for (;;) {
@@ -447,15 +467,15 @@ struct DifMachine {
           ph = D_FINISH;
           break;
         }
-        const double dF = h.p_e2 - h.pdp_e2;
+        const Real dF = h.p_e2 - h.pdp_e2;
         const bool updated = (h.updp || dF > 0);
-        double dL = 0.0;
+        Real dL = Real(0.0);
         for (int i = 0; i < M; ++i) dL += h.dp[i] * (h.mu * h.dp[i] + h.jte[i]);
-        h.accepted = (dL > 0.0 && dF > 0.0) ? 1 : 0;
+        h.accepted = (dL > Real(0.0) && dF > Real(0.0)) ? 1 : 0;
         if (h.accepted) {  // damping update uses dF, dL of this step: do it now, they are not kept
-          double t = (2.0 * dF / dL - 1.0);
-          t = 1.0 - t * t * t;
-          h.mu = h.mu * ((t >= kOneThird) ? t : kOneThird);
+          Real t = (Real(2.0) * dF / dL - Real(1.0));
+          t = Real(1.0) - t * t * t;
+          h.mu = h.mu * ((t >= Real(kOneThird)) ? t : Real(kOneThird));
         }
         if (updated) {
           ++h.updjac;
@@ -465,7 +485,7 @@ struct DifMachine {
                                 // iteration, as in the reference
             h.sel_j ^= 1;
             unpack_lower<M>(s + 1, cool.spec_jtj);
-            const double *g = s + 1 + SumLayout<M>::NL + (h.accepted ? 0 : M);
+            const Real *g = s + 1 + SumLayout<M>::NL + (h.accepted ? 0 : M);
             for (int i = 0; i < M; ++i) cool.spec_jte[i] = g[i];
           } else {
             clear_req(h, req);
@@ -567,13 +587,13 @@ struct DifMachine {
       LM_PHASE(D_SOLVE) {
         LM_STAMP(2);
         if (h.jte_inf <= c.o.eps1) {  // lm_core.c:676-680
-          h.dp_l2 = 0.0;
+          h.dp_l2 = Real(0.0);
           h.stop = 1;
           ph = D_FINISH;
           break;
         }
         if (h.k == 0) {  // lm_core.c:683-687
-          double t = -DBL_MAX;
+          Real t = -LmLimits<Real>::max();
           for (int i = 0; i < M; ++i)
             if (cool.diag[i] > t) t = cool.diag[i];
           h.mu = c.o.tau * t;
@@ -586,9 +606,9 @@ struct DifMachine {
           ph = D_REJECT;
           break;
         }
-        h.dp_l2 = 0.0;
+        h.dp_l2 = Real(0.0);
         for (int i = 0; i < M; ++i) {
-          const double t = h.dp[i];
+          const Real t = h.dp[i];
           cool.pdp[i] = h.p[i] + t;
           h.dp_l2 += t * t;
         }
@@ -597,7 +617,7 @@ struct DifMachine {
           ph = D_FINISH;
           break;
         }
-        if (h.dp_l2 >= (h.p_l2 + c.o.eps2) / (kEpsilon * kEpsilon)) {
+        if (h.dp_l2 >= (h.p_l2 + c.o.eps2) / (Real(kEpsilon) * Real(kEpsilon))) {
           h.stop = 4;
           ph = D_FINISH;
           break;
@@ -623,15 +643,15 @@ struct DifMachine {
         c.info[1] = h.p_e2;
         c.info[2] = h.jte_inf;
         c.info[3] = h.dp_l2;
-        double t = -DBL_MAX;
+        Real t = -LmLimits<Real>::max();
         for (int i = 0; i < M; ++i)
           if (t < h.jtj[i * M + i]) t = h.jtj[i * M + i];
         c.info[4] = h.mu / t;
-        c.info[5] = (double)h.k;
-        c.info[6] = (double)h.stop;
-        c.info[7] = (double)h.nfev;
-        c.info[8] = (double)h.njap;
-        c.info[9] = (double)h.nlss;
+        c.info[5] = (Real)h.k;
+        c.info[6] = (Real)h.stop;
+        c.info[7] = (Real)h.nfev;
+        c.info[8] = (Real)h.njap;
+        c.info[9] = (Real)h.nlss;
         if (c.want_covar) lu_covar<M>(h.jtj, c.covar, h.p_e2, c.n);
         c.ret = (h.stop != 4 && h.stop != 7) ? h.k : kLmError;
         clear_req(h, req);
@@ -647,7 +667,7 @@ struct DifMachine {
 // projected LM step; if it does not reduce the error enough, Schnabel's backtracking line search
 // along it; if that is not a descent direction or fails, a projected-gradient search.
 // =================================================================================================
-template <int M>
+template <int M, class Real = double>
 struct BcMachine {
   enum Phase : int {
     B_INIT_EVAL = 1, B_ITER_TOP, B_AFTER_JAC, B_SOLVE, B_AFTER_LM_EVAL, B_AFTER_LM_NORM, B_LM_JUDGE, B_LS_PROLOGUE,
@@ -655,10 +675,10 @@ struct BcMachine {
     B_END_ITER, B_FINISH, B_DONE
   };
   struct Cold {  // configuration + results (see DifMachine for the Hot/Cold rationale)
-    FitOptions o;
+    FitOptionsT<Real> o;
     int itmax, n, want_covar;
     int has_lb, has_ub, has_dscl;
-    double lb[M], ub[M], dscl[M];
+    Real lb[M], ub[M], dscl[M];
     int infeasible_mask, bad_input;
     int analytic_jac;  // 1: dlevmar_bc_der (caller's Jacobian): no nfev correction at the end (lmbc_core.c:1119-1124)
     int multi;         // candidates evaluated per pass in the projected-gradient search (1 = one at a time).  The
@@ -666,29 +686,29 @@ struct BcMachine {
                        // next points are known before the current one has been judged, so K of them share a sweep.
                        // Candidates are judged in the reference's order and only the judged ones count in nfev:
                        // the trajectory and info[] are exactly those of the one-at-a-time search.
-    double p_start[M];
-    double info[kInfoSz], covar[M * M];
+    Real p_start[M];
+    Real info[kInfoSz], covar[M * M];
     int ret;
   };
   struct Core {  // everything an LM step reads or writes, except the request it leaves
     int phase, k, stop, nu, nfev, njev, nlss, gprev;
-    double p[M], mu, p_e2, jte_inf, p_l2, dp_l2, pdp_e2;
-    double jtj[M * M], jte[M], dp[M], pdp[M];
-    double t, gdp;
+    Real p[M], mu, p_e2, jte_inf, p_l2, dp_l2, pdp_e2;
+    Real jtj[M * M], jte[M], dp[M], pdp[M];
+    Real t, gdp;
     int ls_first, ls_left;
     int pg_n, pg_single;  // candidates in flight; force the next projected-gradient request to a single candidate
   };
   struct Cool {  // the less busy half of the state (see Hot)
-    double init_e2, keep_max, diag[M], t0;
+    Real init_e2, keep_max, diag[M], t0;
     // line-search locals (lmbc_core.c:218-225)
-    double ls_f0, ls_lambda, ls_plmbda, ls_pfpls, ls_tlmbda, ls_rmnlmb, ls_slp;
+    Real ls_f0, ls_lambda, ls_plmbda, ls_pfpls, ls_tlmbda, ls_rmnlmb, ls_slp;
   };
   // Core + Cool + the request.  run() takes them separately, so that a kernel can step on a REGISTER copy of Core
   // while the rest stays in LDS (resident_fit.hip: the sweeping waves read the request there; with Cool in registers as
   // well, hipcc spilled ~100 VGPRs of the step to scratch, which cost more than the LDS round trips it saved)
   struct Hot : Core {
     Cool cool;
-    Request<M> req;
+    Request<M, Real> req;
   };
   // where ONE machine is stepped by a whole wave (every lane the same values): moves the counters and flags of a
   // register copy into scalar registers, so that the step's integer logic and branches run on the scalar unit
@@ -709,15 +729,15 @@ struct BcMachine {
   Cold c;
   Hot h;
 
-  LM_HD static double median3(double a, double b, double c) {  // lmbc_core.c:59-61
+  LM_HD static Real median3(Real a, Real b, Real c) {  // lmbc_core.c:59-61
     return (a >= b) ? ((c >= a) ? a : ((c <= b) ? b : c)) : ((c >= b) ? b : ((c <= a) ? a : c));
   }
   // v must not alias the machine (callers pass a local array): the box is read once, up front -- on the
   // device every dependent re-read of the LDS-resident machine costs a full LDS round trip
-  static LM_HD void project(const Cold &c, double *v) {  // lmbc_core.c:68-88
+  static LM_HD void project(const Cold &c, Real *v) {  // lmbc_core.c:68-88
     const int has_lb = c.has_lb, has_ub = c.has_ub;
     if (!has_lb && !has_ub) return;
-    double lo[M], hi[M];
+    Real lo[M], hi[M];
     for (int i = 0; i < M; ++i) {
       lo[i] = c.lb[i];
       hi[i] = c.ub[i];
@@ -732,19 +752,19 @@ struct BcMachine {
       }
     }
   }
-  static LM_HD void clear_req(const Core &h, Request<M> &req) {
+  static LM_HD void clear_req(const Core &h, Request<M, Real> &req) {
     req.kind = RQ_DONE;
     req.central = 0;
     req.sel_hx = req.sel_j = req.aux = 0;
-    req.dp_l2 = 0.0;
-    req.scal = 1.0;
-    for (int i = 0; i < M; ++i) req.p[i] = req.d[i] = req.q[i] = req.dp[i] = 0.0;
+    req.dp_l2 = Real(0.0);
+    req.scal = Real(1.0);
+    for (int i = 0; i < M; ++i) req.p[i] = req.d[i] = req.q[i] = req.dp[i] = Real(0.0);
   }
   // ask for ||x - f(v)||^2 where v lives in the (possibly scaled) search space.  Only the fields an
   // evaluation pass reads are written (kind, p, scal); v is a local array.
-  static LM_HD void request_eval(const Cold &c, Core &h, Request<M> &req, const double *v, int kind = RQ_EVAL) {
+  static LM_HD void request_eval(const Cold &c, Core &h, Request<M, Real> &req, const Real *v, int kind = RQ_EVAL) {
     req.kind = kind;
-    req.scal = 1.0;
+    req.scal = Real(1.0);
     if (c.has_dscl) {
       for (int i = 0; i < M; ++i) req.p[i] = v[i] * c.dscl[i];
     } else {
@@ -753,15 +773,15 @@ struct BcMachine {
     ++h.nfev;
   }
 
-  LM_HD void start(const double *p0, int n_, const double *lb_, const double *ub_, const double *dscl_,
-                   int itmax_, const double *opts, int want_covar_, int multi_ = 1) {
-    Request<M> &req = h.req;
+  LM_HD void start(const Real *p0, int n_, const Real *lb_, const Real *ub_, const Real *dscl_,
+                   int itmax_, const Real *opts, int want_covar_, int multi_ = 1) {
+    Request<M, Real> &req = h.req;
     Cool &cool = h.cool;
     c.multi = (multi_ < 1) ? 1 : ((multi_ > kMaxCand) ? kMaxCand : multi_);
     h.pg_n = h.pg_single = 0;
     c.o = make_options(opts);
     if (opts) {  // bc_dif reads delta as |opts[4]| and the sign as the FD flavour: lmbc_core.c:1105,1115
-      c.o.forward = (opts[4] >= 0.0);
+      c.o.forward = (opts[4] >= Real(0.0));
       c.o.delta = lm_abs(opts[4]);
     }
     c.itmax = itmax_;
@@ -778,22 +798,22 @@ struct BcMachine {
     h.gprev = 0;
     c.infeasible_mask = 0;
     c.bad_input = 0;
-    h.mu = h.jte_inf = h.p_l2 = h.t = cool.t0 = h.gdp = 0.0;
-    h.p_e2 = cool.init_e2 = h.pdp_e2 = cool.keep_max = 0.0;
-    h.dp_l2 = DBL_MAX;
-    cool.ls_f0 = cool.ls_lambda = cool.ls_plmbda = cool.ls_pfpls = cool.ls_tlmbda = cool.ls_rmnlmb = cool.ls_slp = 0.0;
+    h.mu = h.jte_inf = h.p_l2 = h.t = cool.t0 = h.gdp = Real(0.0);
+    h.p_e2 = cool.init_e2 = h.pdp_e2 = cool.keep_max = Real(0.0);
+    h.dp_l2 = LmLimits<Real>::max();
+    cool.ls_f0 = cool.ls_lambda = cool.ls_plmbda = cool.ls_pfpls = cool.ls_tlmbda = cool.ls_rmnlmb = cool.ls_slp = Real(0.0);
     h.ls_first = 1;
     h.ls_left = 0;
     c.ret = kLmError;
     for (int i = 0; i < M; ++i) {
       h.p[i] = p0[i];
-      c.lb[i] = c.has_lb ? lb_[i] : -DBL_MAX;
-      c.ub[i] = c.has_ub ? ub_[i] : DBL_MAX;
-      c.dscl[i] = c.has_dscl ? dscl_[i] : 1.0;
-      h.jte[i] = cool.diag[i] = h.dp[i] = h.pdp[i] = 0.0;
+      c.lb[i] = c.has_lb ? lb_[i] : -LmLimits<Real>::max();
+      c.ub[i] = c.has_ub ? ub_[i] : LmLimits<Real>::max();
+      c.dscl[i] = c.has_dscl ? dscl_[i] : Real(1.0);
+      h.jte[i] = cool.diag[i] = h.dp[i] = h.pdp[i] = Real(0.0);
     }
-    for (int i = 0; i < M * M; ++i) h.jtj[i] = c.covar[i] = 0.0;
-    for (int i = 0; i < kInfoSz; ++i) c.info[i] = 0.0;
+    for (int i = 0; i < M * M; ++i) h.jtj[i] = c.covar[i] = Real(0.0);
+    for (int i = 0; i < kInfoSz; ++i) c.info[i] = Real(0.0);
     clear_req(h, req);
     h.phase = B_DONE;
     if (c.n < M) {  // lmbc_core.c:440-443
@@ -808,7 +828,7 @@ struct BcMachine {
         }
     if (c.has_dscl)  // lmbc_core.c:456-461
       for (int i = M; i-- > 0;)
-        if (c.dscl[i] <= 0.0) {
+        if (c.dscl[i] <= Real(0.0)) {
           c.bad_input = 3;
           return;
         }
@@ -832,11 +852,11 @@ struct BcMachine {
   // prologue (pow, square roots, divisions) and B_FINISH -- only run when `heavy` is set; otherwise the step stops in front
   // of them with RQ_YIELD.  Pure scheduling: a machine's trajectory does not depend on when its phases run.
   template <bool ONE_LANE = false, bool MULTI = true, bool GATED = false>
-  LM_HD void step(const double *s, double maxabs, bool heavy = true) { run<ONE_LANE, MULTI, GATED>(c, h, h.cool, h.req, s, maxabs, heavy); }
+  LM_HD void step(const Real *s, Real maxabs, bool heavy = true) { run<ONE_LANE, MULTI, GATED>(c, h, h.cool, h.req, s, maxabs, heavy); }
 
   template <bool ONE_LANE, bool MULTI, bool GATED>
-  static LM_HD void run(Cold &c, Core &h, Cool &cool, Request<M> &req, const double *s, double maxabs, bool heavy) {
-    constexpr double alpha = 1e-4, beta = 0.9, gamma = 0.99995, rho = 1e-8, tming = 1e-18, tini = 1.0;
+  static LM_HD void run(Cold &c, Core &h, Cool &cool, Request<M, Real> &req, const Real *s, Real maxabs, bool heavy) {
+    constexpr Real alpha = Real(1e-4), beta = Real(0.9), gamma = Real(0.99995), rho = Real(1e-8), tming = Real(1e-18), tini = Real(1.0);
     int ph = ONE_LANE ? lm_uniform(h.phase) : h.phase;  // scalar register: phase transitions become scalar jumps
     for (;;) {
       if (ONE_LANE) ph = lm_uniform(ph);  // re-assert uniformity: assignments under (formally) divergent branches lose it
@@ -858,8 +878,8 @@ struct BcMachine {
         if (c.has_dscl)
           for (int i = M; i-- > 0;) {
             h.p[i] /= c.dscl[i];
-            if (c.has_ub && c.ub[i] != DBL_MAX) c.ub[i] = c.ub[i] / c.dscl[i];
-            if (c.has_lb && c.lb[i] != -DBL_MAX) c.lb[i] = c.lb[i] / c.dscl[i];
+            if (c.has_ub && c.ub[i] != LmLimits<Real>::max()) c.ub[i] = c.ub[i] / c.dscl[i];
+            if (c.has_lb && c.lb[i] != -LmLimits<Real>::max()) c.lb[i] = c.lb[i] / c.dscl[i];
           }
         ph = B_ITER_TOP;
         break;
@@ -877,35 +897,35 @@ struct BcMachine {
           }
         }
         int nactive = 0, satisfied = 0;  // lmbc_core.c:639-646
-        h.p_l2 = h.jte_inf = 0.0;
+        h.p_l2 = h.jte_inf = Real(0.0);
         for (int i = 0; i < M; ++i) {
           if (c.has_ub && h.p[i] == c.ub[i]) {
             ++nactive;
-            if (h.jte[i] > 0.0) ++satisfied;
+            if (h.jte[i] > Real(0.0)) ++satisfied;
           } else if (c.has_lb && h.p[i] == c.lb[i]) {
             ++nactive;
-            if (h.jte[i] < 0.0) ++satisfied;
+            if (h.jte[i] < Real(0.0)) ++satisfied;
           } else {
-            const double a = lm_abs(h.jte[i]);
+            const Real a = lm_abs(h.jte[i]);
             if (h.jte_inf < a) h.jte_inf = a;
           }
           cool.diag[i] = h.jtj[i * M + i];
           h.p_l2 += h.p[i] * h.p[i];
         }
         if (satisfied == nactive && (h.jte_inf <= c.o.eps1)) {
-          h.dp_l2 = 0.0;
+          h.dp_l2 = Real(0.0);
           h.stop = 1;
           ph = B_FINISH;
           break;
         }
         if (h.k == 0) {  // lmbc_core.c:666-674
           if (!c.has_lb && !c.has_ub) {
-            double m0 = -DBL_MAX;
+            Real m0 = -LmLimits<Real>::max();
             for (int i = 0; i < M; ++i)
               if (cool.diag[i] > m0) m0 = cool.diag[i];
             h.mu = c.o.tau * m0;
           } else
-            h.mu = 0.5 * c.o.tau * h.p_e2;  // Kanzow's starting damping
+            h.mu = Real(0.5) * c.o.tau * h.p_e2;  // Kanzow's starting damping
         }
         ph = B_SOLVE;
         break;
@@ -929,26 +949,26 @@ struct BcMachine {
           for (int i = 0; i < M; ++i) h.jtj[i * M + i] = cool.diag[i];
           break;  // solve again
         }
-        double pc[M], v[M], l2 = 0.0;
+        Real pc[M], v[M], l2 = Real(0.0);
         for (int i = 0; i < M; ++i) {
           pc[i] = h.p[i];
           v[i] = pc[i] + h.dp[i];
         }
         project(c, v);
         for (int i = 0; i < M; ++i) {
-          const double d = v[i] - pc[i];
+          const Real d = v[i] - pc[i];
           h.pdp[i] = v[i];
           h.dp[i] = d;
           l2 += d * d;
         }
         h.dp_l2 = l2;
-        const double pl2 = h.p_l2;
+        const Real pl2 = h.p_l2;
         if (l2 <= c.o.eps2sq * pl2) {
           h.stop = 2;
           ph = B_END_ITER;
           break;
         }
-        if (l2 >= (pl2 + c.o.eps2) / (kEpsilon * kEpsilon)) {
+        if (l2 >= (pl2 + c.o.eps2) / (Real(kEpsilon) * Real(kEpsilon))) {
           h.stop = 4;
           ph = B_END_ITER;
           break;
@@ -989,15 +1009,15 @@ struct BcMachine {
 
       LM_PHASE(B_LM_JUDGE) {
         if (h.pdp_e2 <= gamma * h.p_e2) {  // LM step taken, lmbc_core.c:753-785
-          double dL = 0.0;
+          Real dL = Real(0.0);
           for (int i = 0; i < M; ++i) dL += h.dp[i] * (h.mu * h.dp[i] + h.jte[i]);
-          if (dL > 0.0) {
-            const double dF = h.p_e2 - h.pdp_e2;
-            double q = (2.0 * dF / dL - 1.0);
-            q = 1.0 - q * q * q;
-            h.mu = h.mu * ((q >= kOneThird) ? q : kOneThird);
+          if (dL > Real(0.0)) {
+            const Real dF = h.p_e2 - h.pdp_e2;
+            Real q = (Real(2.0) * dF / dL - Real(1.0));
+            q = Real(1.0) - q * q * q;
+            h.mu = h.mu * ((q >= Real(kOneThird)) ? q : Real(kOneThird));
           } else {
-            const double q = 0.1 * h.pdp_e2;
+            const Real q = Real(0.1) * h.pdp_e2;
             h.mu = (h.mu >= q) ? q : h.mu;
           }
           h.nu = 2;
@@ -1013,47 +1033,47 @@ struct BcMachine {
       LM_GATE(B_LS_PROLOGUE)
       if (!GATED || heavy)
       LM_PHASE(B_LS_PROLOGUE) {  // the LM step was rejected
-        h.gdp = 0.0;  // lmbc_core.c:811-816
+        h.gdp = Real(0.0);  // lmbc_core.c:811-816
         for (int i = 0; i < M; ++i) {
           h.jte[i] = -h.jte[i];
           h.gdp += h.jte[i] * h.dp[i];
         }
-        if (!(h.gdp <= -rho * pow(h.dp_l2, kLsPow / 2.0))) {
+        if (!(h.gdp <= -rho * pow(h.dp_l2, Real(kLsPow) / Real(2.0)))) {
           ph = B_PG_BEGIN;
           break;
         }
         // ---- line-search prologue, lmbc_core.c:227-249 (x = p, f = p_e2, g = jte, step = dp)
-        const double steptl = 1e3 * sqrt(DBL_EPSILON);
-        double pn = sqrt(h.p_l2);
-        const double stepmx = 1e3 * ((pn >= 1.0) ? pn : 1.0);
-        cool.ls_f0 = h.p_e2 * 0.5;
-        double acc = 0.0;
+        const Real steptl = Real(1e3) * sqrt(LmLimits<Real>::eps());
+        Real pn = sqrt(h.p_l2);
+        const Real stepmx = Real(1e3) * ((pn >= Real(1.0)) ? pn : Real(1.0));
+        cool.ls_f0 = h.p_e2 * Real(0.5);
+        Real acc = Real(0.0);
         for (int i = M; i-- > 0;) acc += h.dp[i] * h.dp[i];
-        double sln = sqrt(acc);
+        Real sln = sqrt(acc);
         if (sln > stepmx) {
-          const double scl = stepmx / sln;
+          const Real scl = stepmx / sln;
           for (int i = M; i-- > 0;) h.dp[i] *= scl;
           sln = stepmx;
         }
-        double rln = 0.0;
-        cool.ls_slp = 0.0;
+        Real rln = Real(0.0);
+        cool.ls_slp = Real(0.0);
         for (int i = M; i-- > 0;) {
           cool.ls_slp += h.jte[i] * h.dp[i];
-          const double den = (lm_abs(h.p[i]) >= 1.0) ? lm_abs(h.p[i]) : 1.0;
-          const double rel = lm_abs(h.dp[i]) / den;
+          const Real den = (lm_abs(h.p[i]) >= Real(1.0)) ? lm_abs(h.p[i]) : Real(1.0);
+          const Real rel = lm_abs(h.dp[i]) / den;
           if (rln < rel) rln = rel;
         }
         cool.ls_rmnlmb = steptl / rln;
-        cool.ls_lambda = 1.0;
+        cool.ls_lambda = Real(1.0);
         h.ls_first = 1;
-        cool.ls_plmbda = cool.ls_pfpls = cool.ls_tlmbda = 0.0;
+        cool.ls_plmbda = cool.ls_pfpls = cool.ls_tlmbda = Real(0.0);
         h.ls_left = kLsItMax;
         ph = B_LS_ISSUE;
         break;
       } LM_PHASE_END
 
       LM_PHASE(B_LS_EVAL) {  // lmbc_core.c:269-332
-        const double fpls = 0.5 * s[0];
+        const Real fpls = Real(0.5) * s[0];
         h.pdp_e2 = s[0];
         if (fpls <= cool.ls_f0 + cool.ls_slp * alpha * cool.ls_lambda) {  // satisfactory point
           if (!lm_finite(h.pdp_e2)) {  // lmbc_core.c:828
@@ -1069,29 +1089,29 @@ struct BcMachine {
           break;
         }
         if (!lm_finite(fpls)) {
-          cool.ls_lambda *= 0.1;
+          cool.ls_lambda *= Real(0.1);
           h.ls_first = 1;
         } else {
           if (h.ls_first) {
-            cool.ls_tlmbda = -cool.ls_lambda * cool.ls_slp / ((fpls - cool.ls_f0 - cool.ls_slp) * 2.0);
+            cool.ls_tlmbda = -cool.ls_lambda * cool.ls_slp / ((fpls - cool.ls_f0 - cool.ls_slp) * Real(2.0));
             h.ls_first = 0;
           } else {
-            const double t1 = fpls - cool.ls_f0 - cool.ls_lambda * cool.ls_slp;
-            const double t2 = cool.ls_pfpls - cool.ls_f0 - cool.ls_plmbda * cool.ls_slp;
-            const double t3 = 1.0 / (cool.ls_lambda - cool.ls_plmbda);
-            const double a3 = 3.0 * t3 * (t1 / (cool.ls_lambda * cool.ls_lambda) - t2 / (cool.ls_plmbda * cool.ls_plmbda));
-            const double b = t3 * (t2 * cool.ls_lambda / (cool.ls_plmbda * cool.ls_plmbda) - t1 * cool.ls_plmbda / (cool.ls_lambda * cool.ls_lambda));
-            const double disc = b * b - a3 * cool.ls_slp;
+            const Real t1 = fpls - cool.ls_f0 - cool.ls_lambda * cool.ls_slp;
+            const Real t2 = cool.ls_pfpls - cool.ls_f0 - cool.ls_plmbda * cool.ls_slp;
+            const Real t3 = Real(1.0) / (cool.ls_lambda - cool.ls_plmbda);
+            const Real a3 = Real(3.0) * t3 * (t1 / (cool.ls_lambda * cool.ls_lambda) - t2 / (cool.ls_plmbda * cool.ls_plmbda));
+            const Real b = t3 * (t2 * cool.ls_lambda / (cool.ls_plmbda * cool.ls_plmbda) - t1 * cool.ls_plmbda / (cool.ls_lambda * cool.ls_lambda));
+            const Real disc = b * b - a3 * cool.ls_slp;
             if (disc > b * b)
               cool.ls_tlmbda = (-b + ((a3 < 0) ? -sqrt(disc) : sqrt(disc))) / a3;
             else
               cool.ls_tlmbda = (-b + ((a3 < 0) ? sqrt(disc) : -sqrt(disc))) / a3;
-            if (cool.ls_tlmbda > cool.ls_lambda * 0.5) cool.ls_tlmbda = cool.ls_lambda * 0.5;
+            if (cool.ls_tlmbda > cool.ls_lambda * Real(0.5)) cool.ls_tlmbda = cool.ls_lambda * Real(0.5);
           }
           cool.ls_plmbda = cool.ls_lambda;
           cool.ls_pfpls = fpls;
-          if (cool.ls_tlmbda < cool.ls_lambda * 0.1)
-            cool.ls_lambda *= 0.1;
+          if (cool.ls_tlmbda < cool.ls_lambda * Real(0.1))
+            cool.ls_lambda *= Real(0.1);
           else
             cool.ls_lambda = cool.ls_tlmbda;
         }
@@ -1104,12 +1124,12 @@ struct BcMachine {
           ph = B_PG_BEGIN;
           break;
         }
-        double v[M];
-        const double lam = cool.ls_lambda;
+        Real v[M];
+        const Real lam = cool.ls_lambda;
         for (int i = M; i-- > 0;) v[i] = h.p[i] + lam * h.dp[i];
         project(c, v);
         req.kind = RQ_EVAL;
-        req.scal = 1.0;
+        req.scal = Real(1.0);
         if (!c.has_dscl) {
           for (int i = 0; i < M; ++i) {
             req.p[i] = v[i];
@@ -1137,7 +1157,7 @@ struct BcMachine {
             break;
           }
           cool.keep_max = maxabs;
-          double v[M];
+          Real v[M];
           for (int i = 0; i < M; ++i) v[i] = h.pdp[i];
           request_eval(c, h, req, v, RQ_SCALED);
           --h.nfev;
@@ -1161,25 +1181,25 @@ struct BcMachine {
 
       if constexpr (MULTI)
       LM_PHASE(B_PG_MULTI) {  // judge the candidates of one sweep in the reference's order (lmbc_core.c:886-935)
-        double pc[M], g[M];
+        Real pc[M], g[M];
         for (int i = 0; i < M; ++i) {
           pc[i] = h.p[i];
           g[i] = h.jte[i];
         }
-        const double fold = h.p_e2;
+        const Real fold = h.p_e2;
         const int cnt = h.pg_n;
-        double tt = h.t;
+        Real tt = h.t;
         int next = B_PG_ISSUE;
         for (int j = 0; j < kMaxCand; ++j) {
           if (j >= cnt) break;
-          double v[M], d[M], l2 = 0.0, gd = 0.0;
+          Real v[M], d[M], l2 = Real(0.0), gd = Real(0.0);
           for (int i = 0; i < M; ++i) v[i] = pc[i] - tt * g[i];
           project(c, v);
           for (int i = 0; i < M; ++i) {
             d[i] = v[i] - pc[i];
             l2 += d[i] * d[i];
           }
-          const double fnew = s[j];
+          const Real fnew = s[j];
           if (!lm_finite(fnew)) {  // overflow guard needs max|e| of this candidate: evaluate it alone
             h.pg_single = 1;
             break;
@@ -1193,13 +1213,13 @@ struct BcMachine {
           h.dp_l2 = l2;
           h.pdp_e2 = fnew;
           h.gdp = gd;
-          if (h.gprev && fnew <= fold + 2.0 * 0.99999 * gd) {  // remembered t was too small
+          if (h.gprev && fnew <= fold + Real(2.0) * Real(0.99999) * gd) {  // remembered t was too small
             tt = cool.t0;
             h.gprev = 0;
             tt *= beta;
             break;
           }
-          if (fnew <= fold + 2.0 * alpha * gd) {
+          if (fnew <= fold + Real(2.0) * alpha * gd) {
             h.gprev = 1;
             next = B_COMMIT;
             break;
@@ -1212,19 +1232,19 @@ struct BcMachine {
       } LM_PHASE_END
 
       LM_PHASE(B_PG_JUDGE) {  // lmbc_core.c:923-935
-        double g = 0.0;
+        Real g = Real(0.0);
         for (int i = 0; i < M; ++i) g += h.jte[i] * h.dp[i];
         h.gdp = g;
-        const double fnew = h.pdp_e2, fold = h.p_e2;
-        if (h.gprev && fnew <= fold + 2.0 * 0.99999 * g) {  // remembered t was too small
-          double tt = cool.t0;
+        const Real fnew = h.pdp_e2, fold = h.p_e2;
+        if (h.gprev && fnew <= fold + Real(2.0) * Real(0.99999) * g) {  // remembered t was too small
+          Real tt = cool.t0;
           h.gprev = 0;
           tt *= beta;  // the reference's `continue` still runs the loop increment
           h.t = tt;
           ph = B_PG_ISSUE;
           break;
         }
-        if (fnew <= fold + 2.0 * alpha * g) {
+        if (fnew <= fold + Real(2.0) * alpha * g) {
           h.gprev = 1;
           ph = B_COMMIT;
           break;
@@ -1235,10 +1255,10 @@ struct BcMachine {
       } LM_PHASE_END
 
       LM_PHASE(B_PG_BEGIN) {  // lmbc_core.c:877-885 (jte already holds -J^T e)
-        double g2 = 0.0;
+        Real g2 = Real(0.0);
         for (int i = 0; i < M; ++i) g2 += h.jte[i] * h.jte[i];
         g2 = sqrt(g2);
-        g2 = 100.0 / (1.0 + g2);
+        g2 = Real(100.0) / (Real(1.0) + g2);
         cool.t0 = (g2 <= tini) ? g2 : tini;
         h.t = h.gprev ? h.t : cool.t0;
         ph = B_PG_ISSUE;
@@ -1251,19 +1271,19 @@ struct BcMachine {
           ph = B_END_ITER;
           break;
         }
-        double pc[M], g[M];
+        Real pc[M], g[M];
         for (int i = 0; i < M; ++i) {
           pc[i] = h.p[i];
           g[i] = h.jte[i];
         }
         const int want = MULTI ? (h.pg_single ? 1 : c.multi) : 1;
         h.pg_single = 0;
-        double tt = h.t;
+        Real tt = h.t;
         int cnt = 0;
-        double v0[M];
+        Real v0[M];
         for (int j = 0; j < kMaxCand; ++j) {  // t, t*beta, t*beta^2, ... exactly as the loop increment forms them
           if (j >= want || !(tt > tming)) break;
-          double v[M];
+          Real v[M];
           for (int i = 0; i < M; ++i) v[i] = pc[i] - tt * g[i];
           project(c, v);
           for (int i = 0; i < M; ++i) {
@@ -1274,9 +1294,9 @@ struct BcMachine {
           tt *= beta;
         }
         if (cnt <= 1) {  // one candidate: the plain evaluation request
-          double l2 = 0.0;
+          Real l2 = Real(0.0);
           for (int i = 0; i < M; ++i) {
-            const double d = v0[i] - pc[i];
+            const Real d = v0[i] - pc[i];
             h.pdp[i] = v0[i];
             h.dp[i] = d;
             l2 += d * d;
@@ -1289,15 +1309,15 @@ struct BcMachine {
         h.pg_n = cnt;
         req.kind = RQ_EVAL_MULTI;
         req.nk = cnt;
-        req.scal = 1.0;
+        req.scal = Real(1.0);
         ph = B_PG_MULTI;
         { h.phase = ph; return; }
       } LM_PHASE_END
 
       LM_PHASE(B_COMMIT) {  // lmbc_core.c:950-967
-        h.dp_l2 = 0.0;
+        h.dp_l2 = Real(0.0);
         for (int i = 0; i < M; ++i) {
-          const double d = h.pdp[i] - h.p[i];
+          const Real d = h.pdp[i] - h.p[i];
           h.dp_l2 += d * d;
         }
         if (h.dp_l2 <= c.o.eps2sq * h.p_l2) {
@@ -1345,15 +1365,15 @@ struct BcMachine {
         c.info[1] = h.p_e2;
         c.info[2] = h.jte_inf;
         c.info[3] = h.dp_l2;
-        double m0 = -DBL_MAX;
+        Real m0 = -LmLimits<Real>::max();
         for (int i = 0; i < M; ++i)
           if (m0 < h.jtj[i * M + i]) m0 = h.jtj[i * M + i];
         c.info[4] = h.mu / m0;
-        c.info[5] = (double)h.k;
-        c.info[6] = (double)h.stop;
-        c.info[7] = (double)h.nfev + (c.analytic_jac ? 0.0 : (double)h.njev * (c.o.forward ? (M + 1) : (2 * M)));
-        c.info[8] = (double)h.njev;
-        c.info[9] = (double)h.nlss;
+        c.info[5] = (Real)h.k;
+        c.info[6] = (Real)h.stop;
+        c.info[7] = (Real)h.nfev + (c.analytic_jac ? Real(0.0) : (Real)h.njev * (c.o.forward ? (M + 1) : (2 * M)));
+        c.info[8] = (Real)h.njev;
+        c.info[9] = (Real)h.nlss;
         if (c.want_covar) {
           lu_covar<M>(h.jtj, c.covar, h.p_e2, c.n);
           if (c.has_dscl)
@@ -1376,25 +1396,25 @@ struct BcMachine {
 // iteration asks for the Jacobian's normal equations (RQ_JAC: the pass executor fills J from the caller's
 // jacf instead of finite differences), then tries damped steps until one reduces the error.
 // =================================================================================================
-template <int M>
+template <int M, class Real = double>
 struct DerMachine {
   enum Phase : int { R_INIT_EVAL = 1, R_ITER_TOP, R_AFTER_JAC, R_SOLVE, R_AFTER_EVAL, R_END_ITER, R_FINISH, R_DONE };
   struct Cold {
-    FitOptions o;
+    FitOptionsT<Real> o;
     int itmax, n, want_covar;
-    double info[kInfoSz], covar[M * M];
+    Real info[kInfoSz], covar[M * M];
     int ret;
   };
   struct Core {  // everything an LM step reads or writes, except the request it leaves
     int phase, k, stop, nu, nfev, njev, nlss;
-    double p[M], mu, p_e2, init_e2, jte_inf, p_l2, dp_l2, pdp_e2;
-    double jtj[M * M], jte[M], diag[M], dp[M], pdp[M];
+    Real p[M], mu, p_e2, init_e2, jte_inf, p_l2, dp_l2, pdp_e2;
+    Real jtj[M * M], jte[M], diag[M], dp[M], pdp[M];
   };
   // Core + Cool + the request.  run() takes them separately, so that a kernel can step on a REGISTER copy of Core
   // while the rest stays in LDS (resident_fit.hip: the sweeping waves read the request there; with Cool in registers as
   // well, hipcc spilled ~100 VGPRs of the step to scratch, which cost more than the LDS round trips it saved)
   struct Hot : Core {
-    Request<M> req;
+    Request<M, Real> req;
   };
   // where ONE machine is stepped by a whole wave (every lane the same values): moves the counters and flags of a
   // register copy into scalar registers, so that the step's integer logic and branches run on the scalar unit
@@ -1410,17 +1430,17 @@ struct DerMachine {
   Cold c;
   Hot h;
 
-  static LM_HD void clear_req(const Core &h, Request<M> &req) {
+  static LM_HD void clear_req(const Core &h, Request<M, Real> &req) {
     req.kind = RQ_DONE;
     req.central = 0;
     req.sel_hx = req.sel_j = req.aux = 0;
-    req.dp_l2 = 0.0;
-    req.scal = 1.0;
-    for (int i = 0; i < M; ++i) req.p[i] = req.d[i] = req.q[i] = req.dp[i] = 0.0;
+    req.dp_l2 = Real(0.0);
+    req.scal = Real(1.0);
+    for (int i = 0; i < M; ++i) req.p[i] = req.d[i] = req.q[i] = req.dp[i] = Real(0.0);
   }
 
-  LM_HD void start(const double *p0, int n_, int itmax_, const double *opts, int want_covar_) {
-    Request<M> &req = h.req;
+  LM_HD void start(const Real *p0, int n_, int itmax_, const Real *opts, int want_covar_) {
+    Request<M, Real> &req = h.req;
     c.o = make_options(opts);
     c.itmax = itmax_;
     c.n = n_;
@@ -1428,15 +1448,15 @@ struct DerMachine {
     h.k = h.stop = 0;
     h.nu = 2;
     h.nfev = h.njev = h.nlss = 0;
-    h.mu = h.jte_inf = h.p_l2 = h.p_e2 = h.init_e2 = h.pdp_e2 = 0.0;
-    h.dp_l2 = DBL_MAX;
+    h.mu = h.jte_inf = h.p_l2 = h.p_e2 = h.init_e2 = h.pdp_e2 = Real(0.0);
+    h.dp_l2 = LmLimits<Real>::max();
     c.ret = kLmError;
     for (int i = 0; i < M; ++i) {
       h.p[i] = p0[i];
-      h.jte[i] = h.diag[i] = h.dp[i] = h.pdp[i] = 0.0;
+      h.jte[i] = h.diag[i] = h.dp[i] = h.pdp[i] = Real(0.0);
     }
-    for (int i = 0; i < M * M; ++i) h.jtj[i] = c.covar[i] = 0.0;
-    for (int i = 0; i < kInfoSz; ++i) c.info[i] = 0.0;
+    for (int i = 0; i < M * M; ++i) h.jtj[i] = c.covar[i] = Real(0.0);
+    for (int i = 0; i < kInfoSz; ++i) c.info[i] = Real(0.0);
     clear_req(h, req);
     if (c.n < M) {  // lm_core.c:121-124
       h.phase = R_DONE;
@@ -1448,10 +1468,10 @@ struct DerMachine {
   }
 
   template <bool ONE_LANE = false>
-  LM_HD void step(const double *s, double maxabs) { run<ONE_LANE>(c, h, h.req, s, maxabs); }
+  LM_HD void step(const Real *s, Real maxabs) { run<ONE_LANE>(c, h, h.req, s, maxabs); }
 
   template <bool ONE_LANE>
-  static LM_HD void run(Cold &c, Core &h, Request<M> &req, const double *s, double /*maxabs*/) {
+  static LM_HD void run(Cold &c, Core &h, Request<M, Real> &req, const Real *s, Real /*maxabs*/) {
     int ph = ONE_LANE ? lm_uniform(h.phase) : h.phase;
     for (;;) {
       if (ONE_LANE) ph = lm_uniform(ph);  // re-assert uniformity: assignments under (formally) divergent branches lose it
@@ -1472,21 +1492,21 @@ struct DerMachine {
       LM_PHASE(R_AFTER_JAC) {  // lm_core.c:262-291
         unpack_lower<M>(s, h.jtj);
         for (int i = 0; i < M; ++i) h.jte[i] = s[SumLayout<M>::NL + i];
-        h.p_l2 = h.jte_inf = 0.0;
+        h.p_l2 = h.jte_inf = Real(0.0);
         for (int i = 0; i < M; ++i) {
-          const double t = lm_abs(h.jte[i]);
+          const Real t = lm_abs(h.jte[i]);
           if (h.jte_inf < t) h.jte_inf = t;
           h.diag[i] = h.jtj[i * M + i];
           h.p_l2 += h.p[i] * h.p[i];
         }
         if (h.jte_inf <= c.o.eps1) {
-          h.dp_l2 = 0.0;
+          h.dp_l2 = Real(0.0);
           h.stop = 1;
           ph = R_FINISH;
           break;
         }
         if (h.k == 0) {
-          double t = -DBL_MAX;
+          Real t = -LmLimits<Real>::max();
           for (int i = 0; i < M; ++i)
             if (h.diag[i] > t) t = h.diag[i];
           h.mu = c.o.tau * t;
@@ -1502,13 +1522,13 @@ struct DerMachine {
           ph = R_END_ITER;
           break;
         }
-        double dL = 0.0;
+        Real dL = Real(0.0);
         for (int i = 0; i < M; ++i) dL += h.dp[i] * (h.mu * h.dp[i] + h.jte[i]);
-        const double dF = h.p_e2 - h.pdp_e2;
-        if (dL > 0.0 && dF > 0.0) {
-          double t = (2.0 * dF / dL - 1.0);
-          t = 1.0 - t * t * t;
-          h.mu = h.mu * ((t >= kOneThird) ? t : kOneThird);
+        const Real dF = h.p_e2 - h.pdp_e2;
+        if (dL > Real(0.0) && dF > Real(0.0)) {
+          Real t = (Real(2.0) * dF / dL - Real(1.0));
+          t = Real(1.0) - t * t * t;
+          h.mu = h.mu * ((t >= Real(kOneThird)) ? t : Real(kOneThird));
           h.nu = 2;
           for (int i = 0; i < M; ++i) h.p[i] = h.pdp[i];
           h.p_e2 = h.pdp_e2;
@@ -1535,9 +1555,9 @@ struct DerMachine {
         const int solved = lu_solve<M>(h.jtj, h.jte, h.dp);
         ++h.nlss;
         if (solved) {
-          h.dp_l2 = 0.0;
+          h.dp_l2 = Real(0.0);
           for (int i = 0; i < M; ++i) {
-            const double t = h.dp[i];
+            const Real t = h.dp[i];
             h.pdp[i] = h.p[i] + t;
             h.dp_l2 += t * t;
           }
@@ -1546,7 +1566,7 @@ struct DerMachine {
             ph = R_END_ITER;
             break;
           }
-          if (h.dp_l2 >= (h.p_l2 + c.o.eps2) / (kEpsilon * kEpsilon)) {
+          if (h.dp_l2 >= (h.p_l2 + c.o.eps2) / (Real(kEpsilon) * Real(kEpsilon))) {
             h.stop = 4;
             ph = R_END_ITER;
             break;
@@ -1606,15 +1626,15 @@ struct DerMachine {
         c.info[1] = h.p_e2;
         c.info[2] = h.jte_inf;
         c.info[3] = h.dp_l2;
-        double t = -DBL_MAX;
+        Real t = -LmLimits<Real>::max();
         for (int i = 0; i < M; ++i)
           if (t < h.jtj[i * M + i]) t = h.jtj[i * M + i];
         c.info[4] = h.mu / t;
-        c.info[5] = (double)h.k;
-        c.info[6] = (double)h.stop;
-        c.info[7] = (double)h.nfev;
-        c.info[8] = (double)h.njev;
-        c.info[9] = (double)h.nlss;
+        c.info[5] = (Real)h.k;
+        c.info[6] = (Real)h.stop;
+        c.info[7] = (Real)h.nfev;
+        c.info[8] = (Real)h.njev;
+        c.info[9] = (Real)h.nlss;
         if (c.want_covar) lu_covar<M>(h.jtj, c.covar, h.p_e2, c.n);
         c.ret = (h.stop != 4 && h.stop != 7) ? h.k : kLmError;
         clear_req(h, req);

@@ -96,6 +96,28 @@ double dlevmar_R2(void (*func)(double *p, double *hx, int m, int n, void *adata)
  * programs); the fitter itself solves its 3 x 3 systems in device registers.  Re-entrant, unlike the reference's. */
 int dAx_eq_b_LU_noLapack(double *A, double *B, double *x, int m);
 
+/* ---- single-precision twins: levmar/levmar.h:208-231 (slevmar_der / _dif / _bc_der / _bc_dif; the reference instantiates
+ * them from the same *_core.c sources with LM_REAL = float, lm.c:43-63), :340 (sAx_eq_b_LU_noLapack), :364 (slevmar_chkjac),
+ * :381-383 (slevmar_stddev / _corcoef / _R2).  Same semantics as the d-prefixed entry points above, all arithmetic in
+ * float.  The callbacks are host code evaluated on the host (generic path, 1 <= m <= 8); the n-sized work -- residuals,
+ * FD Jacobian fill, J^T J / J^T e, Broyden update -- runs on the device.  The BRDF application itself is double-only
+ * (brdfdata.cpp:1058, :1119), so there is no registered-model shortcut for these. */
+int slevmar_der(void (*func)(float *p, float *hx, int m, int n, void *adata), void (*jacf)(float *p, float *j, int m, int n, void *adata),
+                float *p, float *x, int m, int n, int itmax, float *opts, float *info, float *work, float *covar, void *adata);
+int slevmar_dif(void (*func)(float *p, float *hx, int m, int n, void *adata), float *p, float *x, int m, int n, int itmax, float *opts,
+                float *info, float *work, float *covar, void *adata);
+int slevmar_bc_der(void (*func)(float *p, float *hx, int m, int n, void *adata), void (*jacf)(float *p, float *j, int m, int n, void *adata),
+                   float *p, float *x, int m, int n, float *lb, float *ub, float *dscl, int itmax, float *opts, float *info, float *work,
+                   float *covar, void *adata);
+int slevmar_bc_dif(void (*func)(float *p, float *hx, int m, int n, void *adata), float *p, float *x, int m, int n, float *lb, float *ub,
+                   float *dscl, int itmax, float *opts, float *info, float *work, float *covar, void *adata);
+void slevmar_chkjac(void (*func)(float *p, float *hx, int m, int n, void *adata), void (*jacf)(float *p, float *j, int m, int n, void *adata),
+                    float *p, int m, int n, void *adata, float *err);
+float slevmar_stddev(float *covar, int m, int i);
+float slevmar_corcoef(float *covar, int m, int i, int j);
+float slevmar_R2(void (*func)(float *p, float *hx, int m, int n, void *adata), float *p, float *x, int m, int n, void *adata);
+int sAx_eq_b_LU_noLapack(float *A, float *B, float *x, int m);
+
 /* Declares that `func` has the semantics of the reference's BRDFFunc (brdfdata.cpp:969-989): adata
  * points to a struct laid out like brdf_extra_data and the value depends on modelInfo.  A host
  * function pointer cannot run on the GPU; registration is how the drop-in entry points know they

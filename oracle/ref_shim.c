@@ -46,3 +46,81 @@ void ref_brdf_chkjac(int model, double *angles, int n, double *p, double *err)
   d.modelInfo = model;
   dlevmar_chkjac(orc_brdf_func, orc_brdf_jac, p, 3, n, &d, err);
 }
+
+/* ---- single-precision test problems (ours: textbook NLLS functions written for float callbacks; the reference's
+ * lmdemo.c problems are double-only).  They drive the REFERENCE's slevmar_* (tests/golden/gen_golden.py ->
+ * tests/golden/slevmar_kat.json) and, by address, the product's slevmar_* on the GPU box. */
+#include <math.h>
+void sp_rosenbrock(float *p, float *x, int m, int n, void *d)
+{
+  (void)m; (void)n; (void)d;
+  x[0] = 10.0f * (p[1] - p[0] * p[0]);
+  x[1] = 1.0f - p[0];
+}
+void sp_rosenbrock_jac(float *p, float *j, int m, int n, void *d)
+{
+  (void)m; (void)n; (void)d;
+  j[0] = -20.0f * p[0]; j[1] = 10.0f;
+  j[2] = -1.0f;         j[3] = 0.0f;
+}
+void sp_wood(float *p, float *x, int m, int n, void *d)
+{
+  (void)m; (void)n; (void)d;
+  x[0] = 10.0f * (p[1] - p[0] * p[0]);
+  x[1] = 1.0f - p[0];
+  x[2] = sqrtf(90.0f) * (p[3] - p[2] * p[2]);
+  x[3] = 1.0f - p[2];
+  x[4] = sqrtf(10.0f) * (p[1] + p[3] - 2.0f);
+  x[5] = (p[1] - p[3]) / sqrtf(10.0f);
+}
+void sp_meyer(float *p, float *x, int m, int n, void *d)
+{
+  int i;
+  (void)m; (void)d;
+  for (i = 0; i < n; ++i) {
+    const float u = 0.45f + 0.05f * (float)i;
+    x[i] = p[0] * expf(10.0f * p[1] / (u + p[2]) - 13.0f);
+  }
+}
+void sp_helval(float *p, float *x, int m, int n, void *d)
+{
+  const float pi = 3.14159265358979f;
+  float theta;
+  (void)m; (void)n; (void)d;
+  if (p[0] < 0.0f)
+    theta = atanf(p[1] / p[0]) / (2.0f * pi) + 0.5f;
+  else if (p[0] > 0.0f)
+    theta = atanf(p[1] / p[0]) / (2.0f * pi);
+  else
+    theta = (p[1] >= 0.0f) ? 0.25f : -0.25f;
+  x[0] = 10.0f * (p[2] - 10.0f * theta);
+  x[1] = 10.0f * (sqrtf(p[0] * p[0] + p[1] * p[1]) - 1.0f);
+  x[2] = p[2];
+}
+void sp_helval_jac(float *p, float *j, int m, int n, void *d)
+{
+  const float pi = 3.14159265358979f;
+  const float r2 = p[0] * p[0] + p[1] * p[1], r = sqrtf(r2);
+  (void)m; (void)n; (void)d;
+  j[0] = 50.0f * p[1] / (pi * r2); j[1] = -50.0f * p[0] / (pi * r2); j[2] = 10.0f;
+  j[3] = 10.0f * p[0] / r;         j[4] = 10.0f * p[1] / r;          j[5] = 0.0f;
+  j[6] = 0.0f;                     j[7] = 0.0f;                      j[8] = 1.0f;
+}
+void sp_hatfldb(float *p, float *x, int m, int n, void *d)
+{
+  int i;
+  (void)n; (void)d;
+  x[0] = p[0] - 1.0f;
+  for (i = 1; i < m; ++i) x[i] = p[i - 1] - sqrtf(p[i]);
+}
+void sp_hatfldb_jac(float *p, float *j, int m, int n, void *d)
+{
+  int i, k;
+  (void)d;
+  for (i = 0; i < n * m; ++i) j[i] = 0.0f;
+  j[0] = 1.0f;
+  for (k = 1; k < m; ++k) {
+    j[k * m + k - 1] = 1.0f;
+    j[k * m + k] = -0.5f / sqrtf(p[k]);
+  }
+}

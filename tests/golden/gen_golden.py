@@ -6,6 +6,7 @@
                    regenerated from the seed, not stored).  This pins the fits no reference-owned test pins.
   lmdemo_kat.json  the reference's own known answers: lmdemo.c problems run through the compiled
                    reference (the same numbers as SURVEY.md section 4, here with full precision).
+  slevmar_kat.json the single-precision twins: the compiled reference's slevmar_* on float test problems (ours, ref_shim.c)
   model_values.json 64 model values per BRDF model from the restated callback (brdfdata.cpp:969-989
                    arithmetic; Ward is build-defined).
 """
@@ -20,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from brdf_amd import synth  # noqa: E402
 from tests import oracle_libs as L  # noqa: E402
-from tests.kat_problems import PROBLEMS, OPTS, run_problem  # noqa: E402
+from tests.kat_problems import PROBLEMS, OPTS, SOPTS, SPROBLEMS, run_problem, run_sproblem  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -46,6 +47,13 @@ def main():
                      "p": [float.hex(v) for v in p], "info": [float.hex(v) for v in info],
                      "covar": None if covar is None else [float.hex(v) for v in covar]})
     json.dump({"opts": list(OPTS), "kats": kats}, open(os.path.join(HERE, "lmdemo_kat.json"), "w"), indent=1)
+
+    skats = []  # single precision: the reference's slevmar_* on the float problems of oracle/ref_shim.c
+    for name, pr in SPROBLEMS.items():
+        r, p, info, covar = run_sproblem(L.ref, pr)
+        skats.append({"name": name, "entry": pr["kind"], "ret": int(r), "p": [float.hex(float(v)) for v in p],
+                      "info": [float.hex(float(v)) for v in info], "covar": None if covar is None else [float.hex(float(v)) for v in covar]})
+    json.dump({"opts": list(SOPTS), "kats": skats}, open(os.path.join(HERE, "slevmar_kat.json"), "w"), indent=1)
 
     vals = []
     for model in (0, 1, 2):

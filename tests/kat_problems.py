@@ -81,3 +81,46 @@ def run_problem(lib, prefix, pr, ref_lib=None):
             r = fn(fp(pr["f"]), ptr(p), ptr(x), m, n, ptr(lb), ptr(ub), None, pr["itmax"], ptr(opts), ptr(info), None,
                    None, None)
     return r, p, info, covar
+
+
+# ---- single precision (slevmar_*, levmar.h:208-310): float problems of oracle/ref_shim.c (ours), starting points and
+# boxes chosen here; the known answers are what the compiled REFERENCE's slevmar_* returns (tests/golden/slevmar_kat.json)
+FM = 3.4028234663852886e38
+SOPTS = (1e-3, 1e-7, 1e-7, 1e-12, 1e-4)
+SPROBLEMS = {
+    "ros_der": dict(kind="der", f="sp_rosenbrock", j="sp_rosenbrock_jac", p=[-1.2, 1.0], x=[0, 0], itmax=200),
+    "ros_dif": dict(kind="dif", f="sp_rosenbrock", p=[-1.2, 1.0], x=[0, 0], itmax=200),
+    "wood_dif": dict(kind="dif", f="sp_wood", p=[-3, -1, -3, -1], x=[0] * 6, itmax=500),
+    "meyer_dif": dict(kind="dif", f="sp_meyer", p=[8.85, 4.0, 2.5], x=MEYER_X, itmax=500, covar=True),
+    "helval_der": dict(kind="der", f="sp_helval", j="sp_helval_jac", p=[-1.0, 0.0, 0.0], x=[0, 0, 0], itmax=200, covar=True),
+    "ros_bc_der": dict(kind="bc_der", f="sp_rosenbrock", j="sp_rosenbrock_jac", p=[-2, 1], x=[0, 0], lb=[-FM, -1.5], ub=[FM, FM], itmax=200),
+    "ros_bc_dif": dict(kind="bc_dif", f="sp_rosenbrock", p=[-2, 1], x=[0, 0], lb=[-FM, -1.5], ub=[0.5, FM], itmax=200),
+    "hatfldb_bc_der": dict(kind="bc_der", f="sp_hatfldb", j="sp_hatfldb_jac", p=[.1] * 4, x=[0] * 4, lb=[0] * 4, ub=[FM, 0.8, FM, FM], itmax=500),
+    "hatfldb_bc_dif": dict(kind="bc_dif", f="sp_hatfldb", p=[.1] * 4, x=[0] * 4, lb=[0] * 4, ub=[FM, 0.8, FM, FM], itmax=500, covar=True),
+}
+
+
+def run_sproblem(lib, pr, ref_lib=None):
+    """one float problem through `lib`'s slevmar_* (callbacks by address from ref_lib, default lib) -> ret, p, info, covar (float32)"""
+    src = ref_lib or lib
+    F = C.POINTER(C.c_float)
+    fp = lambda name: C.cast(getattr(src, name), C.c_void_p)  # noqa: E731
+    f32 = lambda v: None if v is None else np.ascontiguousarray(np.asarray(v, dtype=np.float32))  # noqa: E731
+    ptr = lambda a: None if a is None else a.ctypes.data_as(F)  # noqa: E731
+    p, x = f32(pr["p"]).copy(), f32(pr["x"])
+    m, n = p.size, x.size
+    info, opts = np.zeros(10, dtype=np.float32), f32(SOPTS)
+    covar = np.zeros(m * m, dtype=np.float32) if pr.get("covar") else None
+    if pr["kind"] == "dif":
+        r = lib.slevmar_dif(fp(pr["f"]), ptr(p), ptr(x), m, n, pr["itmax"], ptr(opts), ptr(info), None, ptr(covar), None)
+    elif pr["kind"] == "der":
+        r = lib.slevmar_der(fp(pr["f"]), fp(pr["j"]), ptr(p), ptr(x), m, n, pr["itmax"], ptr(opts), ptr(info), None, ptr(covar), None)
+    else:
+        lb, ub = f32(pr["lb"]), f32(pr["ub"])
+        if pr["kind"] == "bc_der":
+            r = lib.slevmar_bc_der(fp(pr["f"]), fp(pr["j"]), ptr(p), ptr(x), m, n, ptr(lb), ptr(ub), None, pr["itmax"], ptr(opts),
+                                   ptr(info), None, ptr(covar), None)
+        else:
+            r = lib.slevmar_bc_dif(fp(pr["f"]), ptr(p), ptr(x), m, n, ptr(lb), ptr(ub), None, pr["itmax"], ptr(opts), ptr(info), None,
+                                   ptr(covar), None)
+    return r, p, info, covar

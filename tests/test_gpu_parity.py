@@ -640,6 +640,54 @@ def test_lmdemo_known_answers_through_the_product_abi(gpu, capfd):
     capfd.readouterr()
 
 
+@pytest.mark.skipif(L.ref is None, reason="the float problem functions live in oracle/_ref")
+def test_single_precision_twins_replay_the_reference(gpu, capfd):
+    """slevmar_dif / _der / _bc_dif / _bc_der (levmar.h:208-231): the machines and the
+    n-sized kernels instantiated with Real = float, as the reference instantiates its *_core.c files (lm.c:43-63).  The
+    fixtures are what the compiled reference's own slevmar_* returns on nine float problems (tests/golden/gen_golden.py);
+    with the sums formed in the reference's order (n*m <= 65536) the product replays them BIT FOR BIT -- solution,
+    info[] (iteration / evaluation / Jacobian / solve counts included) and covariance.  Also the float utilities."""
+    torch, brdf_amd, dev = gpu
+    from brdf_amd._lib import F, lib
+    from tests.kat_problems import SPROBLEMS, run_sproblem
+    gold = {k["name"]: k for k in json.load(open(os.path.join(HERE, "golden", "slevmar_kat.json")))["kats"]}
+    assert set(gold) == set(SPROBLEMS)
+    f32 = lambda v: np.array([float.fromhex(s) for s in v], dtype=np.float32)  # noqa: E731
+    for name, pr in SPROBLEMS.items():
+        r, p, info, covar = run_sproblem(lib, pr, ref_lib=L.ref)
+        g = gold[name]
+        assert r == g["ret"], (name, r, g["ret"])
+        assert np.array_equal(p, f32(g["p"])), (name, p, f32(g["p"]))
+        assert np.array_equal(info, f32(g["info"])), (name, info, f32(g["info"]))
+        if g["covar"] is not None:
+            assert np.array_equal(covar, f32(g["covar"]), equal_nan=True), (name, covar)
+    capfd.readouterr()
+    # utilities: stddev / corcoef / R2 / chkjac / the LU solver, against the reference's own float versions
+    cov = np.array([4.0, 1.0, 1.0, 9.0], dtype=np.float32)
+    fp = lambda a: a.ctypes.data_as(F)  # noqa: E731
+    for fn in ("slevmar_stddev", "slevmar_corcoef", "slevmar_R2"):
+        getattr(L.ref, fn).restype = C.c_float
+    assert lib.slevmar_stddev(fp(cov), 2, 1) == L.ref.slevmar_stddev(fp(cov), 2, 1) == 3.0
+    assert lib.slevmar_corcoef(fp(cov), 2, 0, 1) == L.ref.slevmar_corcoef(fp(cov), 2, 0, 1)
+    pm = np.array([2.5, 6.2, 3.5], dtype=np.float32)
+    from tests.kat_problems import MEYER_X
+    xm = np.array(MEYER_X, dtype=np.float32)
+    fm = C.cast(L.ref.sp_meyer, C.c_void_p)
+    assert lib.slevmar_R2(fm, fp(pm), fp(xm), 3, 16, None) == L.ref.slevmar_R2(fm, fp(pm.copy()), fp(xm), 3, 16, None)
+    ph = np.array([-1.0, 0.5, 0.25], dtype=np.float32)
+    e1, e2 = np.zeros(3, dtype=np.float32), np.zeros(3, dtype=np.float32)
+    fh, jh = C.cast(L.ref.sp_helval, C.c_void_p), C.cast(L.ref.sp_helval_jac, C.c_void_p)
+    lib.slevmar_chkjac(fh, jh, fp(ph), 3, 3, None, fp(e1))
+    L.ref.slevmar_chkjac(fh, jh, fp(ph.copy()), 3, 3, None, fp(e2))
+    assert np.all(e1 > 0.5) and np.max(np.abs(e1 - e2)) <= 0.05  # (log10 of float rounding noise: device log10f vs glibc's)
+    A = np.array([4, -2, 1, 3, 6, -4, 2, 1, 8], dtype=np.float32)
+    B = np.array([12, -25, 32], dtype=np.float32)
+    x1, x2 = np.zeros(3, dtype=np.float32), np.zeros(3, dtype=np.float32)
+    assert lib.sAx_eq_b_LU_noLapack(fp(A.copy()), fp(B.copy()), fp(x1), 3) == 1
+    assert L.ref.sAx_eq_b_LU_noLapack(fp(A.copy()), fp(B.copy()), fp(x2), 3) == 1
+    assert np.array_equal(x1, x2)
+
+
 def test_unregistered_brdf_callback_takes_the_generic_path(gpu):
     """an application callback that was NOT registered still works (it is called on the host); large n uses the
     deterministic tree, so parity is to tolerance"""
