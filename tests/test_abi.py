@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_symbols():
     text = open(os.path.join(ROOT, "include", "brdf_levmar.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    names = re.findall(r"^(?:int|void|double|long long|const char \*)\s*\*?\s*(\w+)\s*\(", text, flags=re.M)
+    names = re.findall(r"^(?:int|void|double|float|long long|const char \*)\s*\*?\s*(\w+)\s*\(", text, flags=re.M)
     return sorted(set(names))
 
 
