@@ -90,12 +90,15 @@ __global__ __launch_bounds__(THREADS, (batch_waves_per_simd<THREADS, SPT>())) vo
 
   // ---- LM state machine in LDS, stepped by lane 0 ---------------------------------------------------------
   if (tid == 0) {
-    const double *p0 = ctx.p + (size_t)fit * kM;
-    const double *opts = ctx.has_opts ? ctx.opts : nullptr;
+    // (locals, not pointers into the by-value ctx: taking its members' addresses parks the whole struct in scratch)
+    const double p0[kM] = {ctx.p[(size_t)fit * kM], ctx.p[(size_t)fit * kM + 1], ctx.p[(size_t)fit * kM + 2]};
+    const double ov[5] = {ctx.opts[0], ctx.opts[1], ctx.opts[2], ctx.opts[3], ctx.opts[4]};
+    const double lbv[kM] = {ctx.lb[0], ctx.lb[1], ctx.lb[2]}, ubv[kM] = {ctx.ub[0], ctx.ub[1], ctx.ub[2]};
+    const double *opts = ctx.has_opts ? ov : nullptr;
     if constexpr (METHOD == 0) {
       sm.start(p0, n, ctx.itmax, opts, 0, /*speculative=*/1);
     } else if constexpr (METHOD == 1) {
-      sm.start(p0, n, ctx.has_lb ? ctx.lb : nullptr, ctx.has_ub ? ctx.ub : nullptr, nullptr, ctx.itmax, opts, 0, ctx.multi);
+      sm.start(p0, n, ctx.has_lb ? lbv : nullptr, ctx.has_ub ? ubv : nullptr, nullptr, ctx.itmax, opts, 0, ctx.multi);
       sm.c.analytic_jac = ctx.analytic;
     } else {
       sm.start(p0, n, ctx.itmax, opts, 0);
@@ -339,12 +342,14 @@ __global__ __launch_bounds__(kWave, (METHOD == 0 ? 4 : 2)) void batch_fit_rows_k
     const bool run = row_live && !declined;
 
     if (run && leader) {
-      const double *p0 = ctx.p + (size_t)fit * kM;
-      const double *opts = ctx.has_opts ? ctx.opts : nullptr;
+      const double p0[kM] = {ctx.p[(size_t)fit * kM], ctx.p[(size_t)fit * kM + 1], ctx.p[(size_t)fit * kM + 2]};
+      const double ov[5] = {ctx.opts[0], ctx.opts[1], ctx.opts[2], ctx.opts[3], ctx.opts[4]};
+      const double lbv[kM] = {ctx.lb[0], ctx.lb[1], ctx.lb[2]}, ubv[kM] = {ctx.ub[0], ctx.ub[1], ctx.ub[2]};
+      const double *opts = ctx.has_opts ? ov : nullptr;
       if constexpr (METHOD == 0)
         m.start(p0, n, ctx.itmax, opts, 0, /*speculative=*/1);
       else
-        m.start(p0, n, ctx.has_lb ? ctx.lb : nullptr, ctx.has_ub ? ctx.ub : nullptr, nullptr, ctx.itmax, opts, 0);
+        m.start(p0, n, ctx.has_lb ? lbv : nullptr, ctx.has_ub ? ubv : nullptr, nullptr, ctx.itmax, opts, 0);
     }
     __syncthreads();
 

@@ -40,9 +40,12 @@ __global__ __launch_bounds__(kWave, W) void lane_fit_kernel(BatchCtx ctx, int *q
   const int lane = threadIdx.x;
   const int n = ctx.n;
   const int S = ctx.S;
-  const double *opts = ctx.has_opts ? ctx.opts : nullptr;
-  const double *lb = ctx.has_lb ? ctx.lb : nullptr;
-  const double *ub = ctx.has_ub ? ctx.ub : nullptr;
+  // (locals, not pointers into the by-value ctx: taking its members' addresses parks the whole struct in scratch)
+  const double ov[5] = {ctx.opts[0], ctx.opts[1], ctx.opts[2], ctx.opts[3], ctx.opts[4]};
+  const double lbv[kM] = {ctx.lb[0], ctx.lb[1], ctx.lb[2]}, ubv[kM] = {ctx.ub[0], ctx.ub[1], ctx.ub[2]};
+  const double *opts = ctx.has_opts ? ov : nullptr;
+  const double *lb = ctx.has_lb ? lbv : nullptr;
+  const double *ub = ctx.has_ub ? ubv : nullptr;
 
   BcMachine<kM> m;
   m.h.req.kind = RQ_DONE;
@@ -97,7 +100,8 @@ __global__ __launch_bounds__(kWave, W) void lane_fit_kernel(BatchCtx ctx, int *q
           }
           if (FAST) ctx.flags[f] = bad ? kNeedsExact : 0;
           if (!(FAST && bad)) {
-            m.start(ctx.p + (size_t)f * kM, n, lb, ub, nullptr, ctx.itmax, opts, 0, 1);
+            const double p0[kM] = {ctx.p[(size_t)f * kM], ctx.p[(size_t)f * kM + 1], ctx.p[(size_t)f * kM + 2]};
+            m.start(p0, n, lb, ub, nullptr, ctx.itmax, opts, 0, 1);
             m.c.analytic_jac = ctx.analytic;
             if (m.h.req.kind == RQ_DONE) {  // refused by start() (n < m, inconsistent box): lmbc_core.c:440-454
               if (ctx.ret) ctx.ret[f] = kLmError;

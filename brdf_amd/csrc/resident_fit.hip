@@ -71,7 +71,7 @@ constexpr long long kSpinBudgetTicks = 200000000LL;  // default budget per wait:
 
 typedef unsigned long long u64;
 
-struct ResidentCtl {  // zeroed before every launch (uploaded together with the machine)
+struct ResidentCtl {  // never zeroed between launches: a word is "set" when it equals the launch's id (ResidentCtx::launch_id)
   unsigned abort;
   unsigned domain_bad;
   unsigned pad[30];
@@ -82,7 +82,11 @@ struct ResidentCtx {
   u64 *rows;            // [2][kMaxGroups][kRowWords][kGroup] tagged granules; every tag stored so far is <= tag_base
   u64 *groups;          // [2][kReplicas][kRowWords][kMaxGroups]: sums over groups of 16 workgroups, same granule format
   ResidentCtl *ctl;
-  const void *machine0;  // DifMachine<3> / BcMachine<3> as started by the host
+  unsigned launch_id;    // nonzero, different for every launch on this workspace
+  // what the machine is started from (single fits: every workgroup starts its own copy, as the batched kernels do; the
+  // host starts one too, for the argument checks and warnings of the entry point, but nothing is uploaded)
+  double p0[kM], opts[5], lb[kM], ub[kM], dscl[kM];
+  int itmax, has_opts, has_lb, has_ub, has_dscl, want_covar, multi, analytic;
   Mailbox *mbox;
   int n;
   unsigned tag_base;  // tags of this launch are tag_base + epoch + 1: the rows need no zeroing between launches
@@ -298,9 +302,9 @@ __device__ __forceinline__ bool gather_block(const ResidentCtx &ctx, __amdgpu_bu
       return true;
     }
     if ((spins & 63u) == 63u) {  // (wave-uniform)
-      if (__hip_atomic_load(&ctx.ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
+      if (__hip_atomic_load(&ctx.ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ctx.launch_id ||
           (long long)wall_clock64() - t0 > ctx.spin_ticks) {
-        __hip_atomic_store(&ctx.ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ctx.ctl->abort, ctx.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return false;
       }
     }
@@ -553,23 +557,49 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
     if (bctx.flags[fit] != kNeedsExact) return;  // exact kernel: only the fits the fast kernel declined
   }
 
-  if constexpr (BATCHED) {  // the machine is started here (all 64 lanes of the control wave, identical values)
-    if (wave == 0) {
-      const double *p0 = bctx.p + (size_t)fit * kM;
-      const double *opts = bctx.has_opts ? bctx.opts : nullptr;
-      if constexpr (METHOD == 0) {
-        sm.start(p0, n, bctx.itmax, opts, 0, /*speculative=*/1);
-      } else if constexpr (METHOD == 1) {
-        sm.start(p0, n, bctx.has_lb ? bctx.lb : nullptr, bctx.has_ub ? bctx.ub : nullptr, nullptr, bctx.itmax, opts, 0, bctx.multi);
-        sm.c.analytic_jac = bctx.analytic;
-      } else {
-        sm.start(p0, n, bctx.itmax, opts, 0);
+  // The machine is started here, by all 64 lanes of the control wave (identical values): a fit costs ONE launch and no
+  // upload.  (The first version uploaded a host-started machine + two zeroed control words through a pinned staging block
+  // before every launch: ~25 us of a 550 us fit; passing the 1.4 KB machine as a kernel ARGUMENT was worse still -- the
+  // argument segment is host memory and 256 workgroups read it over the host link.)
+  if (wave == 0) {
+    // (the arguments are copied into locals first: handing start() pointers INTO the by-value argument structs makes hipcc
+    // spill the whole struct to scratch and serve every later ctx.field access from there -- measured +1.3 us per pass)
+    double p0[kM], opts[5], lb[kM], ub[kM], dscl[kM];
+    int itmax, has_opts, has_lb, has_ub, has_dscl = 0, want_covar = 0, multi, analytic;
+    if constexpr (BATCHED) {
+#pragma unroll
+      for (int i = 0; i < kM; ++i) {
+        p0[i] = bctx.p[(size_t)fit * kM + i];
+        lb[i] = bctx.lb[i];
+        ub[i] = bctx.ub[i];
+        dscl[i] = 1.0;
       }
+#pragma unroll
+      for (int i = 0; i < 5; ++i) opts[i] = bctx.opts[i];
+      itmax = bctx.itmax, has_opts = bctx.has_opts, has_lb = bctx.has_lb, has_ub = bctx.has_ub, multi = bctx.multi, analytic = bctx.analytic;
+    } else {
+#pragma unroll
+      for (int i = 0; i < kM; ++i) {
+        p0[i] = ctx.p0[i];
+        lb[i] = ctx.lb[i];
+        ub[i] = ctx.ub[i];
+        dscl[i] = ctx.dscl[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 5; ++i) opts[i] = ctx.opts[i];
+      itmax = ctx.itmax, has_opts = ctx.has_opts, has_lb = ctx.has_lb, has_ub = ctx.has_ub, has_dscl = ctx.has_dscl;
+      want_covar = ctx.want_covar, multi = ctx.multi, analytic = ctx.analytic;
     }
-  } else {  // the started machine, written by the host before the launch
-    const unsigned *src = reinterpret_cast<const unsigned *>(ctx.machine0);
-    unsigned *dst = reinterpret_cast<unsigned *>(&sm);
-    for (int w = tid; w < (int)(sizeof(Machine) / 4); w += kRThreads) dst[w] = src[w];
+    const double *po = has_opts ? opts : nullptr;
+    if constexpr (METHOD == 0) {
+      sm.start(p0, n, itmax, po, want_covar, /*speculative=*/1);
+    } else if constexpr (METHOD == 1) {
+      sm.start(p0, n, has_lb ? lb : nullptr, has_ub ? ub : nullptr, has_dscl ? dscl : nullptr, itmax, po, want_covar, multi);
+      sm.c.analytic_jac = analytic;
+    } else {
+      sm.start(p0, n, itmax, po, want_covar);
+    }
+    (void)analytic;
   }
   if (tid == 0) s_abort = s_bad = 0;
   if (tid <= kM) dp_prev[tid] = 0.0;
@@ -617,7 +647,7 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
     if constexpr (BATCHED) {
       if (FAST && bad) s_bad = 1;  // benign race: every writer stores 1
     } else {
-      if (FAST && bad) __hip_atomic_store(&ctx.ctl->domain_bad, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (FAST && bad) __hip_atomic_store(&ctx.ctl->domain_bad, ctx.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (kControlFromLds && wave == 0) {  // park the control wave's samples in LDS
 #pragma unroll
@@ -649,14 +679,13 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
     long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long last_ = clock64();
     long long n_jac = 0;
-    // The machine is stepped where it lives, in LDS.  Two register variants were measured and kept out: a register copy of
-    // the busy half (Machine::Core) made for every step cost more than it saved (170 LDS operations to copy in and out:
-    // 9600 against 8100 cycles per step); keeping Core in this wave's registers for the whole fit (-DBRDF_CORE_IN_REGS; the
-    // sweep runs from LDS with a rolled loop, so the ~90 registers are free) came out even (8170 against 8350 cycles): the
-    // step is a chain of ~1000 dependent fp64 operations on one wave (LM_STAMP sections per step: judging the trial 1070
-    // cycles, decide + iteration top 1780, gradient 940, the 3x3 LU 2300, stop tests + request 1080), not LDS latency.
-    // dlevmar_bc_dif's machine (line search, 8 projected-gradient candidates) does not fit next to its own step code
-    // (160 VGPRs spilled): it always steps in LDS.
+    // The machine is stepped where it lives, in LDS.  Register variants were built and measured (production builds, 10^6-sample
+    // Ward dlevmar_dif, us per pass): Machine::Core (the busy half, ~45 doubles + the counters) kept in this wave's registers
+    // for the whole fit 11.29 against 10.53 in LDS -- although the step itself got shorter in the stamped build (6970 against
+    // 7950 cycles: every `if (h.k < c.itmax ...)` in LDS is a dependent ds_read -> s_waitcnt -> compare -> branch); a register
+    // copy made for every step (170 LDS operations to copy in and out) and all of the machine in registers (105 VGPRs
+    // spilled) were slower still.  -DBRDF_CORE_IN_REGS builds the first variant (never for dlevmar_bc_dif: its machine --
+    // line search, 8 projected-gradient candidates -- spills 160 VGPRs next to its own step code).
 #ifdef BRDF_CORE_IN_REGS
     constexpr bool kCoreInRegs = METHOD != 1;
 #else
@@ -767,7 +796,7 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
         mb->infeasible_mask = sm.c.infeasible_mask;
       else
         mb->infeasible_mask = 0;
-      mb->domain_bad = (int)__hip_atomic_load(&ctx.ctl->domain_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      mb->domain_bad = __hip_atomic_load(&ctx.ctl->domain_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ctx.launch_id ? 1 : 0;
       mb->n_jac = n_jac;
       mb->n_eval = (long long)epoch - n_jac;
       mb->t_first = t_first;
@@ -818,7 +847,6 @@ namespace {
 struct RWorkspace {
   int device = -1, cus = 0;
   char *d_block = nullptr;  // ctl | machine | rows[2][kRowWords][kRowStride]
-  char *h_block = nullptr;  // pinned staging of ctl (zeros) | started machine: ONE upload per fit
   Mailbox *h_mbox = nullptr, *d_mbox = nullptr;
   static constexpr size_t kMachineBytes = 4096;
   static constexpr size_t off_machine = sizeof(ResidentCtl);
@@ -842,7 +870,6 @@ struct RWorkspace {
     HIP_OK(hipMalloc(&d_block, off_rows + rows_bytes + trace_bytes));
     HIP_OK(hipMemset(d_block, 0, off_rows + rows_bytes + trace_bytes));
     tag_base = 0;
-    HIP_OK(hipHostMalloc(&h_block, off_rows, hipHostMallocDefault));
     HIP_OK(hipHostMalloc(&h_mbox, sizeof(Mailbox), hipHostMallocMapped | hipHostMallocCoherent));
     HIP_OK(hipHostGetDevicePointer((void **)&d_mbox, h_mbox, 0));
     return 0;
@@ -856,9 +883,8 @@ int resident_attempt(const StreamFitArgs &a, RWorkspace &ws, bool *retry_exact, 
   static_assert(sizeof(Machine) <= 4096, "resident workspace layout");
   *retry_exact = *unavailable = false;
   const int G = (int)std::min<long long>(ws.cus, std::max<long long>(1, ((long long)a.n + 1023) / 1024));
-  HIP_OK(hipStreamSynchronize(a.stream));  // (no-op on an idle stream) the pinned staging block is about to be rewritten
-  memset(ws.h_block, 0, RWorkspace::off_rows);
-  Machine &m = *reinterpret_cast<Machine *>(ws.h_block + RWorkspace::off_machine);
+  Machine m;  // started here for the entry point's argument checks and warnings only: the kernel starts its own
+  memset(&m, 0, sizeof m);
   if constexpr (METHOD == 0) {
     m.start(a.p, a.n, a.itmax, a.opts, a.covar != nullptr, /*speculative=*/1);
     if (m.h.req.kind == RQ_DONE) {
@@ -890,11 +916,10 @@ int resident_attempt(const StreamFitArgs &a, RWorkspace &ws, bool *retry_exact, 
   }
   Mailbox &mb = *ws.h_mbox;
   memset(&mb, 0, sizeof mb);
-  if (ws.tag_base > 0xF0000000u) {  // tag space nearly used up: start over from zeroed rows
-    HIP_OK(hipMemsetAsync(ws.d_block + RWorkspace::off_rows, 0, RWorkspace::rows_bytes, a.stream));
+  if (ws.tag_base > 0xF0000000u) {  // tag space nearly used up: start over from zeroed rows (and control words)
+    HIP_OK(hipMemsetAsync(ws.d_block, 0, RWorkspace::off_rows + RWorkspace::rows_bytes, a.stream));
     ws.tag_base = 0;
   }
-  HIP_OK(hipMemcpyAsync(ws.d_block, ws.h_block, RWorkspace::off_machine + sizeof(Machine), hipMemcpyHostToDevice, a.stream));
 
   ResidentCtx c;
   c.c0 = a.d_angles;
@@ -904,7 +929,22 @@ int resident_attempt(const StreamFitArgs &a, RWorkspace &ws, bool *retry_exact, 
   c.ctl = reinterpret_cast<ResidentCtl *>(ws.d_block);
   c.rows = reinterpret_cast<u64 *>(ws.d_block + RWorkspace::off_rows);
   c.groups = c.rows + kRowsGranules;
-  c.machine0 = ws.d_block + RWorkspace::off_machine;
+  c.launch_id = ws.tag_base + 1u;  // (tag_base grows by passes + 2 with every launch)
+  for (int i = 0; i < kM; ++i) {
+    c.p0[i] = a.p[i];
+    c.lb[i] = a.lb ? a.lb[i] : 0.0;
+    c.ub[i] = a.ub ? a.ub[i] : 0.0;
+    c.dscl[i] = a.dscl ? a.dscl[i] : 1.0;
+  }
+  for (int i = 0; i < 5; ++i) c.opts[i] = a.opts ? a.opts[i] : 0.0;
+  c.itmax = a.itmax;
+  c.has_opts = a.opts != nullptr;
+  c.has_lb = METHOD == 1 && a.lb != nullptr;
+  c.has_ub = METHOD == 1 && a.ub != nullptr;
+  c.has_dscl = METHOD == 1 && a.dscl != nullptr;
+  c.want_covar = a.covar != nullptr;
+  c.multi = pg_candidates();
+  c.analytic = a.analytic ? 1 : 0;
   c.mbox = ws.d_mbox;
   c.n = a.n;
   c.tag_base = ws.tag_base;
@@ -945,7 +985,7 @@ int resident_attempt(const StreamFitArgs &a, RWorkspace &ws, bool *retry_exact, 
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
   }
   if (!mb.done) {  // aborted: not co-resident / spin budget exhausted.  Tags of unknown epochs were stored: start over
-    (void)hipMemsetAsync(ws.d_block + RWorkspace::off_rows, 0, RWorkspace::rows_bytes, a.stream);
+    (void)hipMemsetAsync(ws.d_block, 0, RWorkspace::off_rows + RWorkspace::rows_bytes, a.stream);
     ws.tag_base = 0;
     *unavailable = true;
     return 0;
