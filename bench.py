@@ -429,7 +429,7 @@ def main_single(args, model):
     roof["note"] = (
         f"achieved = SURVEY.md section 8d's algorithmic bytes ({bpsp} B per sample per LM evaluation: "
         f"{'3' if model == 2 else '2'} planes + measurement, fp64) x 1e6 samples x the launch's evaluations (sweeps_per_launch) / the "
-        "average HIP-event time of a fit's launch (one event pair per fit on the launch stream, its 4 KB upload included); in the "
+        "average HIP-event time of a fit's launch (one event pair per fit on the launch stream); in the "
         "resident regime one launch is a whole fit: the in-launch exchanges and serial LM steps are part of it.  region_us_per_launch "
         "adds the host's gap between two fits; avg_sweeping_launch_us = device clock per evaluation.  traffic = HBM-side bytes per "
         "launch from rocprofv3 FETCH_SIZE (x2 gfx950 correction, calibrated) + WRITE_SIZE, valid only for the sources named in "

@@ -20,21 +20,21 @@
 // in-launch exchange of the per-workgroup partial sums instead of a kernel boundary:
 //
 //   all waves    : sweep -> reduction over the eight waves -> <= 14 partial sums in LDS            (barriers X1, X2)
-//   control wave : publishes them as tagged 8-byte granules {tag : 32, half of a double : 32}, each ONE write-through
-//                  (sc1) store; gathers everybody's in two levels (control_exchange below); folds in a fixed order;
+//   control wave : publishes them as tagged 16-byte cells {lo32, tag, hi32, tag}, each ONE write-through (sc1)
+//                  store; gathers everybody's in two levels (control_exchange below); folds in a fixed order;
 //                  steps ITS OWN copy of the LM state machine (lm_machine.h) -- the same redundant execution as in
-//                  the launch chain of stream_fit.hip, so there is no broadcast hop -- on a REGISTER copy of the
-//                  machine's hot half (every field access of the LDS-resident machine was a dependent LDS round
-//                  trip: 3.6 us per step); builds the next pass's uniforms                          (barrier B)
+//                  the launch chain of stream_fit.hip, so there is no broadcast hop -- in LDS (a register copy of
+//                  the machine's busy half was measured and lost, see the control wave's comment below); builds the
+//                  next pass's uniforms                                                             (barrier B)
 //
 // The speculative dlevmar_dif protocol (lm_machine.h): a trial pass forms the Broyden-updated Jacobian row for the sums
 // only and keeps the update's scalar t = (f(p+Dp) - f(p) - J Dp)/||Dp||^2 per sample; if the machine adopts the update,
 // the NEXT trial pass applies J += t Dp^T on the fly while it reads the row anyway (the first version re-derived t in
 // a separate commit sweep: ~1 us per pass).
 //
-// The granules are recipe R2 of the CDNA guide (cdna_hip_programming.md, Guideline 16: "the data IS the flag"): a
-// granule is one naturally aligned 8-byte word written by one store, so it cannot tear; no flag, no fence, no ordering
-// between granules is needed.  Tags are (launch base + epoch + 1): the tables are never zeroed between fits.  They
+// The cells are recipe R2 of the CDNA guide (cdna_hip_programming.md, Guideline 16: "the data IS the flag"): each
+// 8-byte half {32 bits of the double, tag} is naturally aligned and carries its own tag, so a torn cell reads as "not
+// ready yet"; no flag, no fence, no ordering between cells is needed.  Tags are (launch base + epoch + 1): the tables are never zeroed between fits.  They
 // are double-buffered by epoch parity: a workgroup can be at most one epoch ahead of the slowest one (it needs
 // everybody's row of epoch e+1 before it can publish epoch e+2), so two buffers suffice.  Results do not depend on
 // dispatch order or XCD placement (fold order = workgroup index).  Every spin is bounded by a wall-clock budget: if
@@ -733,6 +733,7 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
         }
       }
       if constexpr (!BATCHED) {  // (a batched fit is one workgroup: sums[] already hold everything)
+       if (gridDim.x > 1) {      // ... and so is a single fit of <= 4096 samples: no exchange, no visibility hops
         if constexpr (METHOD == 0) {
           switch (kind) {
           case RQ_DIF_JAC: alive = control_exchange<SumLayout<kM>::DIF_JAC>(ctx, epoch, sums, &s_abort, st_, last_); break;
@@ -746,6 +747,7 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
           default: alive = control_exchange<1>(ctx, epoch, sums, &s_abort, st_, last_); break;
           }
         }
+       }
       }
       if (!alive) {  // give up: the host sees no `done`, reads ctl->abort and falls back
         __syncthreads();  // B (the other waves read s_abort behind it)

@@ -416,6 +416,34 @@ def test_batch_results_do_not_depend_on_batch_composition(gpu):
         assert np.array_equal(ret, np.concatenate([ra, rb]))
 
 
+def test_batches_on_two_streams_do_not_share_scratch(gpu):
+    """two asynchronous batches issued back to back from ONE host thread on two different streams: the per-thread
+    scratch (exact-path flags, work-queue counters) of the first must not be reset or refilled by the second while the
+    first is still running (batch_fit.hip: BatchScratch orders the second call behind the first with an event).  Both
+    batches hold fits that need the exact path (a cosine of zero) and use the queue-fed kernels (n = 16)."""
+    torch, brdf_amd, dev = gpu
+    model, n, S = 1, 16, 6000
+    sets = []
+    for first in (0, 50000):
+        angles, x, _ = synth.make_surfels(model, n, first=first, count=S)
+        angles[::7, 1, 5] = 0.0  # every seventh fit takes the exact path
+        sets.append((angles, x))
+    p0 = np.tile(np.array(synth.P0[model]), (S, 1))
+    for method in (1, 0):
+        alone = [_batch(gpu, method, model, a, x, p0) for a, x in sets]
+        streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+        dev_in = [(torch.from_numpy(a).to(dev), torch.from_numpy(x).to(dev), torch.from_numpy(p0.copy()).to(dev)) for a, x in sets]
+        torch.cuda.synchronize()
+        outs = []
+        for s, (a, x, p) in zip(streams, dev_in):
+            with torch.cuda.stream(s):
+                outs.append(brdf_amd.fit_batch(method, model, a, x, p, lb=synth.LB, ub=synth.UB, itmax=synth.ITMAX, opts=synth.OPTS))
+        torch.cuda.synchronize()
+        for (p, info, ret), (p_ref, info_ref, ret_ref) in zip(outs, alone):
+            assert np.array_equal(p.cpu().numpy(), p_ref) and np.array_equal(info.cpu().numpy(), info_ref)
+            assert np.array_equal(ret.cpu().numpy(), ret_ref)
+
+
 def test_batch_nonpositive_cosine_takes_exact_path(gpu):
     """a cosine <= 0 cannot go through the cached-log path: that fit is re-done with the reference's pow()
     (pow(0, n) = 0 is a perfectly valid sample for the reference)"""
