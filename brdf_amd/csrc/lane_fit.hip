@@ -30,6 +30,15 @@
 
 namespace brdf {
 
+#ifdef BRDF_LANE_STAMPS  // diagnostic build (make variant EXTRA=-DBRDF_LANE_STAMPS): where a wave's cycles go, summed over all waves
+__device__ long long g_lane_stamps[16];
+#define LSTAMP(i) do { const long long now_ = clock64(); lst_[i] += now_ - llast_; llast_ = now_; } while (0)
+#define LCOUNT(i, v) do { lst_[i] += (v); } while (0)
+#else
+#define LSTAMP(i) do {} while (0)
+#define LCOUNT(i, v) do {} while (0)
+#endif
+
 // W = waves per SIMD the register allocator plans for (512 / 256 / 128 registers per lane at 1 / 2 / 4); LDS allows
 // 5-6 waves per CU at n = 16.  BRDF_HIP_LANE_WAVES picks the variant (measurements: DESIGN.md section 6).
 template <int MODEL, bool FAST, int W>
@@ -52,6 +61,11 @@ __global__ __launch_bounds__(kWave, W) void lane_fit_kernel(BatchCtx ctx, int *q
   int fit = -1;
   bool more = true;  // wave-uniform: the queue may still hold fits
   int since_heavy = 0;
+#ifdef BRDF_LANE_STAMPS
+  long long lst_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long llast_ = clock64();
+  const long long lbegin_ = llast_;
+#endif
 
   // Rounds.  In a round every lane with an evaluation request sweeps its samples and steps its machine.  The EXPENSIVE
   // things -- a Jacobian sweep with the 3x3 solve behind it, the line-search prologue (pow, square roots), the epilogue of
@@ -69,6 +83,10 @@ __global__ __launch_bounds__(kWave, W) void lane_fit_kernel(BatchCtx ctx, int *q
     if (nh == 0 && nl == 0) break;
     const bool heavy = nl == 0 || nh >= ctx.lane_quorum || since_heavy >= ctx.lane_maxwait;
     since_heavy = heavy ? 0 : since_heavy + 1;
+    LSTAMP(0);  // round bookkeeping
+    LCOUNT(heavy ? 8 : 7, 1);
+    LCOUNT(heavy ? 10 : 9, nl);
+    LCOUNT(11, nh);
 
     // ---- refill (heavy rounds): every idle lane takes the next fit of the queue ------------------------------
     bool want = heavy && fit < 0;
@@ -117,6 +135,7 @@ __global__ __launch_bounds__(kWave, W) void lane_fit_kernel(BatchCtx ctx, int *q
       }
     }
 
+    LSTAMP(1);  // refill
     if (fit >= 0) {
       // ---- one pass over this lane's samples, sums in the reference's order -----------------------------------
       const Request<kM> &r = m.h.req;
@@ -131,16 +150,30 @@ __global__ __launch_bounds__(kWave, W) void lane_fit_kernel(BatchCtx ctx, int *q
         if (heavy) {  // lmbc_core.c:595-615: for l = n-1..0 { jtj[i][j] += row[j]*row[i]; jte[i] += row[i]*e[l] }
           PassUniforms<MODEL> u;
           u.build(r, true, ctx.analytic != 0);
-          for (int l = n; l-- > 0;) {
+          auto row = [&](int l, double &e, double *j) {
             const double *d = sp + (size_t)l * NP * kWave;
             const Prep q{d[kWave], NP == 4 ? d[2 * kWave] : 0.0};
-            double f0 = 0.0, j[kM];
+            double f0 = 0.0;
             if (ctx.analytic)  // dlevmar_bc_der: the model's analytic Jacobian (wave-uniform branch)
               model_an_row<MODEL, FAST>(u, d[0], q, f0, j);
             else
               model_fd_row<MODEL, FAST>(u, d[0], q, true, f0, 0.0, false, j);
-            const double e = d[(NP - 1) * kWave] - f0;
-            acc_normal_eq(j, e, s, s + kNL);
+            e = d[(NP - 1) * kWave] - f0;
+          };
+          // two rows per trip (one wave per SIMD: nothing else hides a row's dependent exp chains), accumulated in the
+          // reference's order all the same
+          int l = n;
+          for (; l >= 2; l -= 2) {
+            double ea, eb, ja[kM], jb[kM];
+            row(l - 1, ea, ja);
+            row(l - 2, eb, jb);
+            acc_normal_eq(ja, ea, s, s + kNL);
+            acc_normal_eq(jb, eb, s, s + kNL);
+          }
+          if (l == 1) {
+            double ea, ja[kM];
+            row(0, ea, ja);
+            acc_normal_eq(ja, ea, s, s + kNL);
           }
           do_step = true;
         }
@@ -191,6 +224,7 @@ __global__ __launch_bounds__(kWave, W) void lane_fit_kernel(BatchCtx ctx, int *q
         }
         do_step = true;
       }
+      LSTAMP(heavy ? 3 : 2);  // sweeps of a heavy / light round
       if (do_step) {
         m.template step<false, false, true>(s, mx, heavy);
         if (m.h.req.kind == RQ_DONE) {
@@ -202,8 +236,14 @@ __global__ __launch_bounds__(kWave, W) void lane_fit_kernel(BatchCtx ctx, int *q
           fit = -1;
         }
       }
+      LSTAMP(heavy ? 5 : 4);  // steps (+ result write-out) of a heavy / light round
     }
   }
+#ifdef BRDF_LANE_STAMPS
+  lst_[12] = clock64() - lbegin_;
+  if (lane == 0)
+    for (int i = 0; i < 13; ++i) atomicAdd((unsigned long long *)&g_lane_stamps[i], (unsigned long long)lst_[i]);
+#endif
 }
 
 #define HIP_OK(call)                                                                  \
@@ -269,5 +309,13 @@ int lane_fit_enqueue(int model, bool fast, const BatchCtx &c, int *queue, hipStr
   }
   return 0;
 }
+
+#ifdef BRDF_LANE_STAMPS
+extern "C" int brdf_hip_lane_stamps(long long *out) {  // reads and clears the counters (diagnostic builds only)
+  long long zero[16] = {0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lane_stamps), sizeof(zero)) != hipSuccess) return -1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_lane_stamps), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 }  // namespace brdf
