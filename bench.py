@@ -292,6 +292,8 @@ def main_batched(args):
                              "note": "batched regime: the samples are read from HBM once per fit (min_traffic = 32 B x n x S + 104 B per fit) "
                                      "and the LM iterations run out of registers; the kernel is bound by fp64 VALU issue and the serial LM step, "
                                      "not by HBM (DESIGN.md section 4)"}}
+        # the gathered rows (p, info, ret of every surfel, in surfel order) as one digest: runs on 1, 2, 4, 8 ranks must agree bit for bit
+        line["result_sha256"] = hashlib.sha256(out.cpu().contiguous().numpy().tobytes()).hexdigest()[:16]
         if stub:
             line["stub_checksum"] = float(out[:, :3].sum().item())
         if cpu_base is not None:

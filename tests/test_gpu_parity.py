@@ -812,3 +812,30 @@ def test_single_brdf_call_site_configuration(gpu, n):
     assert r >= 0 and res.ret >= 0
     assert L.rel_err(res.p, p_ref) <= P_TOL, (res.p, p_ref)
     assert abs(res.info[1] - info_ref[1]) <= E_TOL * info_ref[1]
+
+
+def test_bench_on_two_ranks_reproduces_one_rank_bit_for_bit(gpu):
+    """`python bench.py --gpus 2 --workload c5` with real fits: two ranks (here both on this box's one GPU, collectives
+    over gloo -- BRDF_BENCH_DEVICE / BRDF_BENCH_BACKEND, the rehearsal switches) shard the surfels, fit their halves with
+    the HIP kernels and gather: the digest of all fitted rows equals the one-rank run's.  (RCCL itself needs one GPU per
+    rank; the driver's multi-GPU run is the first to use it.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, BRDF_BENCH_BACKEND="gloo", BRDF_BENCH_DEVICE="0")
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    lines = {}
+    for gpus in (1, 2):
+        for entry in ("dif", "bc_dif"):
+            out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--workload", "c5", "--entry", entry,
+                                  "--surfels", "20001", "--steps", "1", "--warmup", "1", "--no-cpu"], capture_output=True, text=True,
+                                 env=env, cwd=root, timeout=600)
+            assert out.returncode == 0, out.stderr[-2000:]
+            js = [l for l in out.stdout.splitlines() if l.startswith("{")]
+            assert len(js) == 1, out.stdout
+            lines[gpus, entry] = json.loads(js[0])
+    for entry in ("dif", "bc_dif"):
+        one, two = lines[1, entry], lines[2, entry]
+        assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and one["config"]["failed_fits"] == two["config"]["failed_fits"] == 0
+        assert one["result_sha256"] == two["result_sha256"] and one["config"]["mean_nfev"] == two["config"]["mean_nfev"]
