@@ -25,12 +25,32 @@
 #include <cstdlib>
 #include <cstring>
 
+#ifdef BRDF_LANE_STAMPS
+#include <hip/hip_runtime.h>
+// per-phase cycles of the machines' run(): a wave walks serially over the phase blocks its lanes are in; the first active
+// lane of every block entered closes the previous interval (one wave per workgroup here, so the state lives in LDS)
+__shared__ long long lp_acc[32];
+__shared__ long long lp_t;
+__shared__ int lp_prev;
+__device__ __forceinline__ bool lane_phase_enter(int x) {
+  const unsigned long long act = __ballot(1);
+  if ((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1) {
+    const long long now = clock64();
+    lp_acc[lp_prev & 31] += now - lp_t;
+    lp_prev = x;
+    lp_t = now;
+  }
+  return true;
+}
+#define LM_PHASE_ENTER(X) lane_phase_enter((int)(X))
+#endif
 #include "batch_fit.h"
 #include "stream_fit.h"
 
 namespace brdf {
 
-#ifdef BRDF_LANE_STAMPS  // diagnostic build (make variant EXTRA=-DBRDF_LANE_STAMPS): where a wave's cycles go, summed over all waves
+#ifdef BRDF_LANE_STAMPS
+__device__ long long g_lane_phase[32];  // diagnostic build (make variant EXTRA=-DBRDF_LANE_STAMPS): where a wave's cycles go, summed over all waves
 __device__ long long g_lane_stamps[16];
 #define LSTAMP(i) do { const long long now_ = clock64(); lst_[i] += now_ - llast_; llast_ = now_; } while (0)
 #define LCOUNT(i, v) do { lst_[i] += (v); } while (0)
@@ -65,6 +85,9 @@ __global__ __launch_bounds__(kWave, W) void lane_fit_kernel(BatchCtx ctx, int *q
   long long lst_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   long long llast_ = clock64();
   const long long lbegin_ = llast_;
+  if (lane < 32) lp_acc[lane] = 0;
+  if (lane == 0) { lp_prev = 0; lp_t = llast_; }
+  __syncthreads();
 #endif
 
   // Rounds.  In a round every lane with an evaluation request sweeps its samples and steps its machine.  The EXPENSIVE
@@ -225,6 +248,9 @@ __global__ __launch_bounds__(kWave, W) void lane_fit_kernel(BatchCtx ctx, int *q
         do_step = true;
       }
       LSTAMP(heavy ? 3 : 2);  // sweeps of a heavy / light round
+#ifdef BRDF_LANE_STAMPS
+      lane_phase_enter(heavy ? 30 : 31);  // (the interval up to here -- sweeps, bookkeeping -- is not a phase's)
+#endif
       if (do_step) {
         m.template step<false, false, true>(s, mx, heavy);
         if (m.h.req.kind == RQ_DONE) {
@@ -238,11 +264,16 @@ __global__ __launch_bounds__(kWave, W) void lane_fit_kernel(BatchCtx ctx, int *q
       }
       LSTAMP(heavy ? 5 : 4);  // steps (+ result write-out) of a heavy / light round
     }
+#ifdef BRDF_LANE_STAMPS
+    lane_phase_enter(0);
+#endif
   }
 #ifdef BRDF_LANE_STAMPS
   lst_[12] = clock64() - lbegin_;
   if (lane == 0)
     for (int i = 0; i < 13; ++i) atomicAdd((unsigned long long *)&g_lane_stamps[i], (unsigned long long)lst_[i]);
+  __syncthreads();
+  if (lane < 32) atomicAdd((unsigned long long *)&g_lane_phase[lane], (unsigned long long)lp_acc[lane]);
 #endif
 }
 
@@ -311,10 +342,12 @@ int lane_fit_enqueue(int model, bool fast, const BatchCtx &c, int *queue, hipStr
 }
 
 #ifdef BRDF_LANE_STAMPS
-extern "C" int brdf_hip_lane_stamps(long long *out) {  // reads and clears the counters (diagnostic builds only)
-  long long zero[16] = {0};
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lane_stamps), sizeof(zero)) != hipSuccess) return -1;
-  return hipMemcpyToSymbol(HIP_SYMBOL(g_lane_stamps), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+extern "C" int brdf_hip_lane_stamps(long long *out) {  // out[0..15] sections, out[16..47] phases; reads and clears (diagnostic builds only)
+  long long zero[32] = {0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lane_stamps), 16 * sizeof(long long)) != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out + 16, HIP_SYMBOL(g_lane_phase), 32 * sizeof(long long)) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_lane_phase), zero, 32 * sizeof(long long)) != hipSuccess) return -1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_lane_stamps), zero, 16 * sizeof(long long)) == hipSuccess ? 0 : -1;
 }
 #endif
 

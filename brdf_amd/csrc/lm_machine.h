@@ -42,7 +42,10 @@ constexpr double kInitMu = 1E-03;
 #endif
 
 // a guarded phase block of BcMachine::run (see there); ONE_LANE: the comparison stays on the scalar unit
-#define LM_PHASE(X) if ((ONE_LANE ? lm_uniform(ph) : ph) == X) do
+#ifndef LM_PHASE_ENTER
+#define LM_PHASE_ENTER(X) true  // diagnostic builds of lane_fit.hip time the phases (a wave's serial walk over its lanes' phases)
+#endif
+#define LM_PHASE(X) if ((ONE_LANE ? lm_uniform(ph) : ph) == X && LM_PHASE_ENTER(X)) do
 #define LM_PHASE_END while (0);
 // in front of a gated block: a GATED step outside a heavy round stops here (RQ_YIELD)
 #define LM_GATE(X)                                    \
@@ -859,6 +862,7 @@ struct BcMachine {
     constexpr Real alpha = Real(1e-4), beta = Real(0.9), gamma = Real(0.99995), rho = Real(1e-8), tming = Real(1e-18), tini = Real(1.0);
     int ph = ONE_LANE ? lm_uniform(h.phase) : h.phase;  // scalar register: phase transitions become scalar jumps
     for (;;) {
+      (void)LM_PHASE_ENTER(29);  // (diagnostic builds: a trip of the dispatch loop starts)
       if (ONE_LANE) ph = lm_uniform(ph);  // re-assert uniformity: assignments under (formally) divergent branches lose it
       // The phases are a chain of guarded blocks in the order control flows through them, not a switch: a lane (or
       // the one stepping lane) walks through every block its phase reaches in ONE trip of this loop -- only a failed

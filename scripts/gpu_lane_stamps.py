@@ -22,7 +22,7 @@ for model in (1, 2):
     for rep in range(2):
         p0 = torch.from_numpy(np.tile(np.array(synth.P0[model]), (S, 1))).to(dev)
         torch.cuda.synchronize()
-        out = (C.c_longlong * 16)()
+        out = (C.c_longlong * 48)()
         raw.brdf_hip_lane_stamps(out)  # clear
         t0 = time.perf_counter()
         p, info, ret = brdf_amd.fit_batch(1, model, a, x, p0, lb=lb, ub=ub, itmax=100, opts=synth.OPTS)
@@ -38,3 +38,8 @@ for model in (1, 2):
     print(f"   rounds: {v[7]} light ({v[2] / lr:.0f} sweep + {v[4] / lr:.0f} step cycles each, {v[9] / lr:.1f} lanes evaluating), "
           f"{v[8]} heavy ({v[1] / hr:.0f} refill + {v[3] / hr:.0f} sweep + {v[5] / hr:.0f} step cycles each, {v[10] / hr:.1f} lanes evaluating)")
     print(f"   lanes wanting a heavy round, average over all rounds: {v[11] / (lr + hr):.1f}")
+    ph = ["outside", "B_INIT_EVAL", "B_ITER_TOP", "B_AFTER_JAC", "B_SOLVE", "B_AFTER_LM_EVAL", "B_AFTER_LM_NORM", "B_LM_JUDGE", "B_LS_PROLOGUE",
+          "B_LS_ISSUE", "B_LS_EVAL", "B_PG_BEGIN", "B_PG_ISSUE", "B_PG_EVAL", "B_PG_NORM", "B_PG_JUDGE", "B_PG_MULTI", "B_COMMIT", "B_END_ITER",
+          "B_FINISH", "B_DONE"] + ["-"] * 8 + ["dispatch trip start", "step entry (heavy round)", "step entry (light round)"]
+    pv = v[16:48]
+    print("   phases of BcMachine::run, % of wave cycles: " + ", ".join(f"{ph[i]} {100.0 * pv[i] / tot:.1f}" for i in range(32) if pv[i] > 0.002 * tot))
