@@ -345,7 +345,9 @@ __device__ __forceinline__ bool control_exchange(const ResidentCtx &ctx, unsigne
       *s_abort = 1;
       return false;
     }
+#ifndef BRDF_TRACE_WORKERS
     RTRACE(ctx, epoch, 6, polls + 1);
+#endif
     fold_block(val);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -370,7 +372,9 @@ __device__ __forceinline__ bool control_exchange(const ResidentCtx &ctx, unsigne
   __builtin_amdgcn_wave_barrier();
   RSTAMP(3);
   RTRACE(ctx, epoch, 4, wall_clock64());
+#ifndef BRDF_TRACE_WORKERS
   RTRACE(ctx, epoch, 7, polls);
+#endif
   return true;
 }
 
@@ -815,6 +819,9 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
 
   // ============================= waves 1..7: register-resident samples ===========================================
   long long wst_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wlast_ = 0;  // (stamps are the control wave's; these are never read)
+#ifdef BRDF_TRACE_WORKERS
+  unsigned wepoch = 0;
+#endif
   for (;;) {
     const int kind = sm.h.req.kind;
     if (kind == RQ_DONE) break;
@@ -826,6 +833,13 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
     double mx = 0.0;
     const double dpp[kM] = {dp_prev[0], dp_prev[1], dp_prev[2]};
     sweep_pass<MODEL, METHOD, FAST>(kind, su, rs, jl, tid, nk, okm, pend, dpp, acc, mx);
+#ifdef BRDF_TRACE_WORKERS  // (diagnostic: when do the register-resident waves finish their sweeps? slots 6, 7 = waves 4, 7)
+    if constexpr (!BATCHED) {
+      if (wave == 4) RTRACE(ctx, wepoch, 6, wall_clock64());
+      if (wave == 7) RTRACE(ctx, wepoch, 7, wall_clock64());
+      ++wepoch;
+    }
+#endif
     reduce_pass<METHOD>(kind, acc, mx, red, sums, wst_, wlast_);
     __syncthreads();  // B: the control wave has stepped the machine
     if (s_abort) return;

@@ -29,4 +29,9 @@ for model, n in cases:
                     v = (t[:, k] - t0) * 0.01
                     print(f"    trace {nm:34s} us after the first workgroup's pass start: min {v.min():6.2f} median {np.median(v):6.2f} max {v.max():6.2f}"
                           + (f" | leaders: min {v[lead].min():6.2f} max {v[lead].max():6.2f}" if k == 3 and lead.any() else ""), flush=True)
+                if os.environ.get("BRDF_TRACE_WORKERS"):
+                    for k, nm in ((6, "wave 4 (SIMD of the control wave) sweep done"), (7, "wave 7 sweep done")):
+                        v = (t[:, k] - t0) * 0.01
+                        print(f"    trace {nm:34s} us after the first workgroup's pass start: min {v.min():6.2f} median {np.median(v):6.2f} max {v.max():6.2f}", flush=True)
+                    continue
                 print(f"    trace polls: level 1 (leaders) {sorted(t[lead, 6].tolist())}  level 2 min {t[:, 7].min()} median {int(np.median(t[:, 7]))} max {t[:, 7].max()}", flush=True)
