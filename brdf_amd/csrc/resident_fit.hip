@@ -164,6 +164,8 @@ struct LdsSamples {
 template <bool UNROLLED, class F>
 __device__ __forceinline__ void for_samples(int nk, F &&f) {
   if constexpr (UNROLLED) {
+    // (one sample per guarded block.  Two per block -- so that the scheduler can interleave two samples' exp / Broyden chains
+    // inside one basic block -- was measured: 28-36 more spilled VGPRs, 539 against 527 us per 10^6-sample dlevmar_dif fit)
 #pragma unroll
     for (int k = 0; k < kRSpt; ++k)
       if (k < nk) f(k);
