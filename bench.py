@@ -187,6 +187,9 @@ def launch_ranks(args, argv):
     return subprocess.run(cmd, cwd=ROOT).returncode
 
 
+FORCE_COLL = False
+
+
 def dist_setup(args):
     import torch
     import torch.distributed as dist
@@ -205,11 +208,32 @@ def dist_setup(args):
     else:
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
-    if world > 1:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+    # BRDF_BENCH_COLLECTIVES=1 (rehearsal): run every collective of the N > 1 path on a ONE-rank communicator as well, so
+    # that the RCCL calls themselves (init, barrier, all_reduce, gather on device tensors) execute on a one-GPU box
+    global FORCE_COLL
+    FORCE_COLL = os.environ.get("BRDF_BENCH_COLLECTIVES") == "1"
+    if world > 1 or FORCE_COLL:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        # RCCL prints a version banner on stdout when its first communicator comes up; stdout is for rank 0's ONE JSON line,
+        # so file descriptor 1 points at stderr while the communicator is created (init + a first barrier)
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group(backend)
+            dist.barrier()
+            if not stub:
+                torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
     return torch, dist, rank, world, backend, dev, stub
 
 
@@ -261,18 +285,18 @@ def main_batched(args):
 
     for _ in range(args.warmup):
         one_step()
-    if world > 1:
+    if world > 1 or FORCE_COLL:
         dist.barrier()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = one_step()
-    if world > 1:
+    if world > 1 or FORCE_COLL:
         dist.barrier()
     sync()
     wall = time.perf_counter() - t0
     wt = torch.tensor([wall], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-    if world > 1:
+    if world > 1 or FORCE_COLL:
         dist.all_reduce(wt, op=dist.ReduceOp.MAX)
     if rank == 0:
         wall = float(wt.item())
@@ -299,7 +323,7 @@ def main_batched(args):
         if cpu_base is not None:
             line["cpu_baseline"] = cpu_base
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or FORCE_COLL:
         dist.destroy_process_group()
     return 0
 
@@ -331,7 +355,7 @@ def main_single(args, model):
         res_np = np.zeros((steps, 13))  # filled inside the timed loop (numpy: ~1 us per row; torch CPU indexing costs ~20 us)
         passes = jac = launches = 0
         dev_us = 0.0
-        if world > 1:
+        if world > 1 or FORCE_COLL:
             dist.barrier()
         torch.cuda.synchronize()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -355,7 +379,7 @@ def main_single(args, model):
         ev1.record()
         results = torch.from_numpy(res_np)
         gathered = None
-        if world > 1:  # the one collective of the job: fitted parameters + info[] of every step -> rank 0
+        if world > 1 or FORCE_COLL:  # the one collective of the job: fitted parameters + info[] of every step -> rank 0
             res_dev = results.to(coll_dev)
             gathered = [torch.empty_like(res_dev) for _ in range(world)] if rank == 0 else None
             dist.gather(res_dev, gathered, dst=0)
@@ -367,7 +391,7 @@ def main_single(args, model):
         stat = torch.tensor([wall, float(results[:, 10].sum().item()) * N_SAMPLES, ev_ms, float(passes), float(jac), dev_us,
                              float(launches), fit_ms],
                             dtype=torch.float64, device=coll_dev)
-        if world > 1:
+        if world > 1 or FORCE_COLL:
             allstat = [torch.empty_like(stat) for _ in range(world)]
             dist.all_gather(allstat, stat)
             allstat = torch.stack(allstat).cpu()
@@ -402,7 +426,7 @@ def main_single(args, model):
         }
 
     if rank != 0:
-        if world > 1:
+        if world > 1 or FORCE_COLL:
             dist.destroy_process_group()
         return 0
 
@@ -472,7 +496,7 @@ def main_single(args, model):
             print("bench.py: PARITY FAILURE against the CPU levmar path", file=sys.stderr)
             rc = 3
     print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or FORCE_COLL:
         dist.destroy_process_group()
     return rc
 

@@ -28,8 +28,9 @@ def gather_results(local: "torch.Tensor", total: int, group=None):
     """
     import torch
     import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return local
+    import os
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and os.environ.get("BRDF_BENCH_COLLECTIVES") != "1"):
+        return local  # (BRDF_BENCH_COLLECTIVES=1: bench.py's rehearsal of the collective on a one-rank communicator)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     per = -(-total // world)
     k = local.shape[1]

@@ -143,7 +143,7 @@ def test_bench_launches_its_own_ranks(tmp_path):
                              cwd=ROOT, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
         js = [l for l in out.stdout.splitlines() if l.startswith("{")]
-        assert len(js) == 1, out.stdout  # exactly one JSON line, from rank 0
+        assert len(js) == 1 and len(out.stdout.strip().splitlines()) == 1, out.stdout  # exactly one line on stdout: rank 0's JSON
         lines[gpus] = json.loads(js[0])
     assert lines[1]["n_gpus"] == 1 and lines[2]["n_gpus"] == 2
     assert lines[2]["config"]["surfels"] == 37 and lines[2]["steps"] == 2
