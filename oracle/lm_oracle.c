@@ -1099,3 +1099,19 @@ int orc_brdf_fit(int method, int model, double *angles, double *x, int n, double
     return orc_dlevmar_bc_der(orc_brdf_func, orc_brdf_jac, p, x, 3, n, lb, ub, NULL, itmax, opts, info, NULL, NULL, &d);
   return orc_dlevmar_bc_dif(orc_brdf_func, p, x, 3, n, lb, ub, NULL, itmax, opts, info, NULL, NULL, &d);
 }
+
+/* S independent fits one after the other -- the shape of CalcBRDFEquation's pixel loop (brdfdata.cpp:1195-1220):
+ * angles[S][3][n], x[S][n], p[S][3] in/out, info[S][10], ret[S].  Returns the number of fits that failed.  (Callers run
+ * several ranges of surfels on several threads: the restatement keeps no static state.) */
+int orc_brdf_fit_batch(int method, int model, double *angles, double *x, long S, int n, double *p, int itmax,
+                       double *opts, double *lb, double *ub, double *info, int *ret)
+{
+  long s;
+  int bad = 0;
+  for (s = 0; s < S; ++s) {
+    const int r = orc_brdf_fit(method, model, angles + s * 3 * n, x + s * n, n, p + 3 * s, itmax, opts, lb, ub, info + 10 * s);
+    if (ret) ret[s] = r;
+    if (r < 0) ++bad;
+  }
+  return bad;
+}

@@ -71,6 +71,10 @@ int orc_dlevmar_bc_dif(orc_func_t f, double *p, double *x, int m, int n, double 
 int orc_brdf_fit(int method, int model, double *angles, double *x, int n, double *p, int itmax,
                  double *opts, double *lb, double *ub, double *info);
 
+/* S fits one after the other (angles[S][3][n], x[S][n], p[S][3] in/out, info[S][10], ret[S]); returns the number of failed fits */
+int orc_brdf_fit_batch(int method, int model, double *angles, double *x, long S, int n, double *p, int itmax,
+                       double *opts, double *lb, double *ub, double *info, int *ret);
+
 #ifdef __cplusplus
 }
 #endif
