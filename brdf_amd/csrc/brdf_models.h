@@ -110,6 +110,34 @@ struct BrdfModel<MODEL_BLINN_PHONG> {
   }
 };
 
+// exp(x) for x <= 0 (Ward's lobe: the argument is -tan^2/alpha^2).  On the device: ocml's own algorithm -- k = rint(x log2 e),
+// r = x - k ln2 in two pieces, the same degree-11 polynomial with the same coefficients, ldexp -- hence the same bits, minus
+// the overflow select at its end, which cannot fire for x <= 0 (the underflow select stays: for arguments like -1e40 -- a
+// vanishing alpha -- the two-piece reduction is garbage and only the select makes the result 0): 3 of the ~85 instructions a
+// trial sweep spends per sample.  A NaN stays a NaN, exp(-inf) = 0, every other value has ocml's bits.
+LM_HD double exp_nonpos(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double k = __builtin_rint(x * __longlong_as_double(0x3ff71547652b82feLL));
+  double r = fma(k, __longlong_as_double((long long)0xbfe62e42fefa39efULL), x);
+  r = fma(k, __longlong_as_double((long long)0xbc7abc9e3b39803fULL), r);
+  double p = fma(r, __longlong_as_double(0x3e5ade156a5dcb37LL), __longlong_as_double(0x3e928af3fca7ab0cLL));
+  p = fma(r, p, __longlong_as_double(0x3ec71dee623fde64LL));
+  p = fma(r, p, __longlong_as_double(0x3efa01997c89e6b0LL));
+  p = fma(r, p, __longlong_as_double(0x3f2a01a014761f6eLL));
+  p = fma(r, p, __longlong_as_double(0x3f56c16c1852b7b0LL));
+  p = fma(r, p, __longlong_as_double(0x3f81111111122322LL));
+  p = fma(r, p, __longlong_as_double(0x3fa55555555502a1LL));
+  p = fma(r, p, __longlong_as_double(0x3fc5555555555511LL));
+  p = fma(r, p, __longlong_as_double(0x3fe000000000000bLL));
+  p = fma(r, p, 1.0);
+  p = fma(r, p, 1.0);
+  const double z = __builtin_ldexp(p, (int)k);
+  return x < __longlong_as_double((long long)0xc090cc0000000000ULL) ? 0.0 : z;  // (-1075: ocml's own underflow select; keeps exp(-inf) = 0)
+#else
+  return exp(x);
+#endif
+}
+
 // Ward (isotropic, build-defined): with a2 = p2^2, t2 = tan^2(theta_h), rinv = 1/sqrt(c0 c2)
 //   x = c0 * ( p0/PI + p1 * ( (1/(4 PI a2)) * exp(-(t2 * (1/a2))) ) * rinv )
 // written with reciprocals so that the per-sample invariants t2 and rinv can be cached.
@@ -132,7 +160,7 @@ struct BrdfModel<MODEL_WARD> {
   template <bool FAST>
   static LM_HD double shape(const Nl &u, double c0, const Prep &q) {
     const Prep v = FAST ? q : ward_invariants(c0, q.q1, q.q2);
-    const double g = exp(-(v.q1 * u.u0));
+    const double g = exp_nonpos(-(v.q1 * u.u0));
     return (u.u1 * g) * v.q2;
   }
   static LM_HD double combine(const Lin &l, double c0, double s) { return c0 * (l.a + l.b * s); }

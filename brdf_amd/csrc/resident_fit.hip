@@ -498,6 +498,8 @@ __device__ __forceinline__ void sweep_pass(int kind, const PassUniforms<MODEL> &
 #pragma unroll
         for (int j = 0; j < kM; ++j) jn[j] = fma(t, u.dp[j], jo[j]);
         double en = x - w, eo = x - h;
+        // (compiling this select into the last slot's copy of the body only -- it is predicated, not branched around, 5 of ~85
+        // instructions -- was measured: 43 spilled VGPRs, 605 against 520 us per fit)
         if (k == nk - 1 && dead(k)) en = eo = jn[0] = jn[1] = jn[2] = 0.0;
         st.set(kFwrk, k, w);
         st.set(kFtb, k, t);
