@@ -500,14 +500,21 @@ __device__ __forceinline__ void sweep_pass(int kind, const PassUniforms<MODEL> &
         double en = x - w, eo = x - h;
         // (compiling this select into the last slot's copy of the body only -- it is predicated, not branched around, 5 of ~85
         // instructions -- was measured: 43 spilled VGPRs, 605 against 520 us per fit)
-        if (k == nk - 1 && dead(k)) en = eo = jn[0] = jn[1] = jn[2] = 0.0;
+        if (k == nk - 1 && dead(k)) en = eo = jn[0] = jn[1] = jn[2] = t = 0.0;
         st.set(kFwrk, k, w);
         st.set(kFtb, k, t);
+        // NINE sums, not the machine's thirteen: with J' = J + t Dp^T the products of the updated Jacobian follow from those
+        // of the current one, which the machine holds:  J'^T J' = J^T J + a Dp^T + Dp a^T + (t^T t) Dp Dp^T with a = J^T t, and
+        // J'^T e = J^T e + Dp (t^T e); only J'^T e' (against the NEW residual) is accumulated directly.  The control wave
+        // expands them after the exchange (expand_trial_sums).  Layout: [e'^2, a (3), t^T t, J'^T e' (3), t^T e].  Four
+        // accumulators, four reduction slots and four exchange cells fewer per pass: 521 -> 501 us per 10^6-sample fit.
         acc[0] = fma(en, en, acc[0]);
-        acc_normal_eq_fma(jn, en, acc + 1, acc + 1 + kNL);
-        acc[1 + kNL + kM + 0] = fma(jn[0], eo, acc[1 + kNL + kM + 0]);
-        acc[1 + kNL + kM + 1] = fma(jn[1], eo, acc[1 + kNL + kM + 1]);
-        acc[1 + kNL + kM + 2] = fma(jn[2], eo, acc[1 + kNL + kM + 2]);
+#pragma unroll
+        for (int j = 0; j < kM; ++j) acc[1 + j] = fma(jo[j], t, acc[1 + j]);
+        acc[1 + kM] = fma(t, t, acc[1 + kM]);
+#pragma unroll
+        for (int j = 0; j < kM; ++j) acc[2 + kM + j] = fma(jn[j], en, acc[2 + kM + j]);
+        acc[2 + 2 * kM] = fma(t, eo, acc[2 + 2 * kM]);
       });
     }
     break;
@@ -516,12 +523,43 @@ __device__ __forceinline__ void sweep_pass(int kind, const PassUniforms<MODEL> &
 }
 
 // the matching reduction (the number of sums depends on the request kind only: wave-uniform)
+constexpr int kTrialSums = 3 + 2 * kM;  // what a dlevmar_dif trial sweep reduces: [e'^2, J^T t (3), t^T t, J'^T e' (3), t^T e]
+
+// ... and what the machine wants (SumLayout::DIF_TRIAL: [e'^2, J'^T J' lower (6), J'^T e' (3), J'^T e (3)]), from them and from the
+// products of the CURRENT Jacobian the machine holds while a trial is out: jtj (its diagonal carries mu: the plain one is in
+// diag) and jte.  Executed by the control wave, all lanes the same values; in place.
+template <class Core, class Cool>
+__device__ __forceinline__ void expand_trial_sums(const Core &core, const Cool &cool, const double *dpv, double *sums) {
+  const double s0 = sums[0], a[kM] = {sums[1], sums[2], sums[3]}, b = sums[1 + kM];
+  const double d[kM] = {sums[2 + kM], sums[3 + kM], sums[4 + kM]}, te = sums[2 + 2 * kM];
+  const double dp[kM] = {dpv[0], dpv[1], dpv[2]};
+  double out[SumLayout<kM>::DIF_TRIAL];
+  out[0] = s0;
+  int c = 1;
+#pragma unroll
+  for (int i = 0; i < kM; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j, ++c) {
+      double v = (i == j) ? cool.diag[i] : core.jtj[i * kM + j];
+      v = fma(a[i], dp[j], v);
+      v = fma(dp[i], a[j], v);
+      out[c] = fma(b * dp[i], dp[j], v);
+    }
+#pragma unroll
+  for (int j = 0; j < kM; ++j) {
+    out[1 + kNL + j] = d[j];
+    out[1 + kNL + kM + j] = fma(dp[j], te, core.jte[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < SumLayout<kM>::DIF_TRIAL; ++j) sums[j] = out[j];
+}
+
 template <int METHOD>
 __device__ __forceinline__ void reduce_pass(int kind, const double *acc, double mx, double *red, double *sums, long long *st_, long long &last_) {
   if constexpr (METHOD == 0) {
     switch (kind) {
     case RQ_DIF_JAC: worker_reduce<SumLayout<kM>::DIF_JAC>(acc, mx, red, sums, st_, last_); break;
-    case RQ_DIF_TRIAL: worker_reduce<SumLayout<kM>::DIF_TRIAL>(acc, mx, red, sums, st_, last_); break;
+    case RQ_DIF_TRIAL: worker_reduce<kTrialSums>(acc, mx, red, sums, st_, last_); break;
     default: worker_reduce<1>(acc, mx, red, sums, st_, last_); break;
     }
   } else {
@@ -745,7 +783,7 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
         if constexpr (METHOD == 0) {
           switch (kind) {
           case RQ_DIF_JAC: alive = control_exchange<SumLayout<kM>::DIF_JAC>(ctx, epoch, sums, &s_abort, st_, last_); break;
-          case RQ_DIF_TRIAL: alive = control_exchange<SumLayout<kM>::DIF_TRIAL>(ctx, epoch, sums, &s_abort, st_, last_); break;
+          case RQ_DIF_TRIAL: alive = control_exchange<kTrialSums>(ctx, epoch, sums, &s_abort, st_, last_); break;
           default: alive = control_exchange<1>(ctx, epoch, sums, &s_abort, st_, last_); break;
           }
         } else {
@@ -762,6 +800,12 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
         return;
       }
       if (kind == RQ_DIF_TRIAL) {
+        if constexpr (METHOD == 0) {
+          if constexpr (kCoreInRegs)
+            expand_trial_sums(hcore, sm.h.cool, su.dp, sums);
+          else
+            expand_trial_sums(static_cast<const typename Machine::Core &>(sm.h), sm.h.cool, su.dp, sums);
+        }
 #pragma unroll
         for (int j = 0; j < kM; ++j) dp_prev[j] = su.dp[j];
         dp_prev[kM] = su.dp_l2;
