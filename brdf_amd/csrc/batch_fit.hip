@@ -232,27 +232,38 @@ __global__ __launch_bounds__(THREADS, (batch_waves_per_simd<THREADS, SPT>())) vo
 #pragma unroll
         for (int k = 0; k < SPT; ++k) {
           const double w = model_value_q<MODEL, FAST>(u, s0[k], pq[k]);
-          double jn[kM];
-          broyden_row(jac[k], w, hx[k], u.dp, u.dp_l2, jn);
+          // broyden_row() (lm_core.c:760-766) spelled out: its scalar t is summed too -- the trial sweep leaves the NINE sums
+          // of device_common.h (kTrialSums), which the stepping wave expands into the machine's thirteen
+          double t = 0.0, jn[kM];
+#pragma unroll
+          for (int l = 0; l < kM; ++l) t += jac[k][l] * u.dp[l];
+          t = (w - hx[k] - t) / u.dp_l2;
+#pragma unroll
+          for (int j = 0; j < kM; ++j) jn[j] = jac[k][j] + t * u.dp[j];
           double en = sx[k] - w, eo = sx[k] - hx[k];
-          if (!ok[k]) en = eo = jn[0] = jn[1] = jn[2] = 0.0;
+          if (!ok[k]) en = eo = jn[0] = jn[1] = jn[2] = t = 0.0;
           wrk[k] = w;
           acc[0] += en * en;
-          acc_normal_eq(jn, en, acc + 1, acc + 1 + kNL);
-          acc[1 + kNL + kM + 0] += jn[0] * eo;
-          acc[1 + kNL + kM + 1] += jn[1] * eo;
-          acc[1 + kNL + kM + 2] += jn[2] * eo;
+#pragma unroll
+          for (int j = 0; j < kM; ++j) acc[1 + j] += jac[k][j] * t;
+          acc[1 + kM] += t * t;
+#pragma unroll
+          for (int j = 0; j < kM; ++j) acc[2 + kM + j] += jn[j] * en;
+          acc[2 + 2 * kM] += t * eo;
         }
-        block_reduce<SumLayout<kM>::DIF_TRIAL, THREADS>(acc, mx, red, sums);
+        block_reduce<kTrialSums, THREADS>(acc, mx, red, sums);
       }
       break;
     default: break;
     }
     if (first_wave) {
-      if (METHOD == 0 && kind == RQ_DIF_TRIAL) {
+      if constexpr (METHOD == 0) {
+        if (kind == RQ_DIF_TRIAL) {
+          expand_trial_sums(static_cast<const typename Machine::Core &>(sm.h), sm.h.cool, su.dp, sums);
 #pragma unroll
-        for (int j = 0; j < kM; ++j) dp_prev[j] = su.dp[j];
-        dp_prev[kM] = su.dp_l2;
+          for (int j = 0; j < kM; ++j) dp_prev[j] = su.dp[j];
+          dp_prev[kM] = su.dp_l2;
+        }
       }
       sm.template step<true>(sums, sums[kSums]);
     }
@@ -446,6 +457,8 @@ __global__ __launch_bounds__(kWave, (METHOD == 0 ? 4 : 2)) void batch_fit_rows_k
       }
       // row reductions: DPP only (every lane takes part; idle rows reduce zeros)
       double sums[kSlots];
+      // (all thirteen sums here, not the nine of the other kernels: expanding them on four divergent row leaders costs more
+      // than the four row reductions it saves -- measured 1.66e7 against 1.94e7 fits/s)
 #pragma unroll
       for (int k = 0; k < kSums; ++k) sums[k] = row_reduce_to_last<OpSum>(acc[k]);
       sums[kSums] = row_reduce_to_last<OpMax>(mx);

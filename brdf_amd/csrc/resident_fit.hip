@@ -522,38 +522,8 @@ __device__ __forceinline__ void sweep_pass(int kind, const PassUniforms<MODEL> &
   }
 }
 
-// the matching reduction (the number of sums depends on the request kind only: wave-uniform)
-constexpr int kTrialSums = 3 + 2 * kM;  // what a dlevmar_dif trial sweep reduces: [e'^2, J^T t (3), t^T t, J'^T e' (3), t^T e]
-
-// ... and what the machine wants (SumLayout::DIF_TRIAL: [e'^2, J'^T J' lower (6), J'^T e' (3), J'^T e (3)]), from them and from the
-// products of the CURRENT Jacobian the machine holds while a trial is out: jtj (its diagonal carries mu: the plain one is in
-// diag) and jte.  Executed by the control wave, all lanes the same values; in place.
-template <class Core, class Cool>
-__device__ __forceinline__ void expand_trial_sums(const Core &core, const Cool &cool, const double *dpv, double *sums) {
-  const double s0 = sums[0], a[kM] = {sums[1], sums[2], sums[3]}, b = sums[1 + kM];
-  const double d[kM] = {sums[2 + kM], sums[3 + kM], sums[4 + kM]}, te = sums[2 + 2 * kM];
-  const double dp[kM] = {dpv[0], dpv[1], dpv[2]};
-  double out[SumLayout<kM>::DIF_TRIAL];
-  out[0] = s0;
-  int c = 1;
-#pragma unroll
-  for (int i = 0; i < kM; ++i)
-#pragma unroll
-    for (int j = 0; j <= i; ++j, ++c) {
-      double v = (i == j) ? cool.diag[i] : core.jtj[i * kM + j];
-      v = fma(a[i], dp[j], v);
-      v = fma(dp[i], a[j], v);
-      out[c] = fma(b * dp[i], dp[j], v);
-    }
-#pragma unroll
-  for (int j = 0; j < kM; ++j) {
-    out[1 + kNL + j] = d[j];
-    out[1 + kNL + kM + j] = fma(dp[j], te, core.jte[j]);
-  }
-#pragma unroll
-  for (int j = 0; j < SumLayout<kM>::DIF_TRIAL; ++j) sums[j] = out[j];
-}
-
+// the matching reduction (the number of sums depends on the request kind only: wave-uniform; a trial sweep leaves kTrialSums:
+// device_common.h)
 template <int METHOD>
 __device__ __forceinline__ void reduce_pass(int kind, const double *acc, double mx, double *red, double *sums, long long *st_, long long &last_) {
   if constexpr (METHOD == 0) {
