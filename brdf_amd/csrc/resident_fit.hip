@@ -178,7 +178,9 @@ __device__ __forceinline__ void for_samples(int nk, F &&f) {
 // Reduction of NS sums and one max over the eight waves: two DPP steps inside each row of 16 lanes leave the sum of
 // every 4 consecutive lanes in lanes 3,7,11,..; those park their values as buf[slot][thread/4]; wave w then owns slots
 // {w, w+8}: each lane adds its two entries and one DPP tree per slot finishes it.  A pure function of NS: reproducible.
-template <int NS>
+// MAX = false (dlevmar_dif: its machine never looks at max |e|): no max slot -- one value less per wave, one 16-byte cell less
+// per row and, with nine sums, one of the four gather instructions of an exchange
+template <int NS, bool MAX = true>
 __device__ __forceinline__ void worker_reduce(const double *acc, double mx, double *buf, double *out, long long *st_, long long &last_) {
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;  // 0..7
@@ -190,33 +192,34 @@ __device__ __forceinline__ void worker_reduce(const double *acc, double mx, doub
     t = t + dpp_move<0x112, 0xf, 0xf>(t, 0.0);  // row_shr:2
     v[k] = t;
   }
-  {
+  if constexpr (MAX) {
     double t = mx;
     t = fmax(t, dpp_move<0x111, 0xf, 0xf>(t, 0.0));
     t = fmax(t, dpp_move<0x112, 0xf, 0xf>(t, 0.0));
     v[NS] = t;
   }
+  constexpr int NV = NS + (MAX ? 1 : 0);  // values per lane
   if ((threadIdx.x & 3) == 3) {
 #pragma unroll
-    for (int k = 0; k <= NS; ++k) buf[k * kRedCols + (threadIdx.x >> 2)] = v[k];
+    for (int k = 0; k < NV; ++k) buf[k * kRedCols + (threadIdx.x >> 2)] = v[k];
   }
   __syncthreads();  // X1
   RSTAMP(6);
   {  // wave w finishes slots w and w + 8 (wave-uniform conditions), the two dependent DPP trees interleaved
     constexpr int NW = kRThreads / kWave;
     const int k0 = wave, k1 = wave + NW;
-    const bool has0 = k0 <= NS, has1 = k1 <= NS;
+    const bool has0 = k0 < NV, has1 = k1 < NV;
     double s0 = 0.0, s1 = 0.0;
     if (has0) {
       const double *src = buf + k0 * kRedCols;
-      s0 = (k0 < NS) ? src[lane] + src[lane + kWave] : fmax(src[lane], src[lane + kWave]);
+      s0 = (k0 < NS || !MAX) ? src[lane] + src[lane + kWave] : fmax(src[lane], src[lane + kWave]);
     }
     if (has1) {
       const double *src = buf + k1 * kRedCols;
-      s1 = (k1 < NS) ? src[lane] + src[lane + kWave] : fmax(src[lane], src[lane + kWave]);
+      s1 = (k1 < NS || !MAX) ? src[lane] + src[lane + kWave] : fmax(src[lane], src[lane + kWave]);
     }
     // (the max slot is slot NS: it is the LAST slot of whichever wave owns it, so at most one of the two is a max)
-    const bool max0 = has0 && k0 == NS, max1 = has1 && k1 == NS;
+    const bool max0 = MAX && has0 && k0 == NS, max1 = MAX && has1 && k1 == NS;
     if (!max0 && !max1) {
       wave_reduce2_to_last<OpSum, OpSum>(s0, s1);
     } else if (max1) {
@@ -273,12 +276,12 @@ __device__ __forceinline__ void put_cell(__amdgpu_buffer_rsrc_t t, unsigned cell
   __builtin_amdgcn_raw_buffer_store_b128(d, t, (int)(cell * 16u), 0, kCacheSc1);
 }
 
-template <int NS>
-__device__ __forceinline__ constexpr bool slot_used(int v) { return v < NS || v == kSums; }
+template <int NS, bool MAX = true>
+__device__ __forceinline__ constexpr bool slot_used(int v) { return v < NS || (MAX && v == kSums); }
 
 // val[j] <- slot 4j + lane/16 of column lane%16 of the block starting at cell `first` (0 where the slot is not used or
 // the column >= ncols)
-template <int NS>
+template <int NS, bool MAX = true>
 __device__ __forceinline__ bool gather_block(const ResidentCtx &ctx, __amdgpu_buffer_rsrc_t t, unsigned first, unsigned tag, int ncols,
                                              double (&val)[4], unsigned *polls) {
   const int lane = threadIdx.x;  // control wave = wave 0
@@ -290,9 +293,9 @@ __device__ __forceinline__ bool gather_block(const ResidentCtx &ctx, __amdgpu_bu
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       d[j] = u32x4{0u, tag, 0u, tag};
-      if ((4 * j < NS) || (4 * j <= kSums && kSums < 4 * j + 4)) {  // (compile time) some row of this instruction is used
+      if ((4 * j < NS) || (MAX && 4 * j <= kSums && kSums < 4 * j + 4)) {  // (compile time) some row of this instruction is used
         const int v = 4 * j + r;
-        if (slot_used<NS>(v) && col < ncols) d[j] = __builtin_amdgcn_raw_buffer_load_b128(t, (int)((first + v * kGroup + col) * 16u), 0, kCacheSc1);
+        if (slot_used<NS, MAX>(v) && col < ncols) d[j] = __builtin_amdgcn_raw_buffer_load_b128(t, (int)((first + v * kGroup + col) * 16u), 0, kCacheSc1);
       }
     }
 #pragma unroll
@@ -315,15 +318,18 @@ __device__ __forceinline__ bool gather_block(const ResidentCtx &ctx, __amdgpu_bu
 }
 
 // folds the 16 columns of every slot: the total of slot 4j + r ends in lane 16r + 15 of val[j] (the max slot by max)
+template <int NS, bool MAX>
 __device__ __forceinline__ void fold_block(double (&val)[4]) {
   const int r = (int)threadIdx.x >> 4;
-  const double mx = row_reduce_to_last<OpMax>(val[kSums / 4]);
+  double mx = 0.0;
+  if constexpr (MAX) mx = row_reduce_to_last<OpMax>(val[kSums / 4]);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) val[j] = row_reduce_to_last<OpSum>(val[j]);
-  if (r == (kSums & 3)) val[kSums / 4] = mx;
+  for (int j = 0; j < 4; ++j)
+    if ((4 * j < NS) || (MAX && j == kSums / 4)) val[j] = row_reduce_to_last<OpSum>(val[j]);  // (compile time: rows in use)
+  if (MAX && r == (kSums & 3)) val[kSums / 4] = mx;
 }
 
-template <int NS>
+template <int NS, bool MAX = true>
 __device__ __forceinline__ bool control_exchange(const ResidentCtx &ctx, unsigned epoch, double *sums, int *s_abort,
                                                  long long *st_, long long &last_) {
   const int lane = threadIdx.x;  // control wave = wave 0
@@ -338,37 +344,37 @@ __device__ __forceinline__ bool control_exchange(const ResidentCtx &ctx, unsigne
   const unsigned my_rows = ((epoch & 1u) * kMaxGroups + grp) * kBlockCells;   // first cell of this group's block
   const unsigned my_groups = (epoch & 1u) * kReplicas * kBlockCells;           // first cell of copy 0 of the group rows
   const bool withhold = (int)epoch == ctx.sabotage_epoch && blockIdx.x == gridDim.x - 1;  // test hook, see ResidentCtx
-  if (slot_used<NS>(lane) && lane <= kSums && !withhold) put_cell(rows, my_rows + lane * kGroup + blockIdx.x % kGroup, tag, sums[lane]);
+  if (slot_used<NS, MAX>(lane) && lane <= kSums && !withhold) put_cell(rows, my_rows + lane * kGroup + blockIdx.x % kGroup, tag, sums[lane]);
 
   double val[4];
   unsigned polls = 0;
   if ((int)blockIdx.x == leader) {  // group leader (workgroup-uniform branch)
-    if (!gather_block<NS>(ctx, rows, my_rows, tag, members, val, &polls)) {
+    if (!gather_block<NS, MAX>(ctx, rows, my_rows, tag, members, val, &polls)) {
       *s_abort = 1;
       return false;
     }
 #ifndef BRDF_TRACE_WORKERS
     RTRACE(ctx, epoch, 6, polls + 1);
 #endif
-    fold_block(val);
+    fold_block<NS, MAX>(val);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const double t = dpp_move<0x15F, 0xf, 0xf>(val[j], 0.0);  // row_newbcast:15: the row's total in all 16 lanes of the row
       const int v = 4 * j + r;
-      if (slot_used<NS>(v) && col < ctx.replicas) put_cell(groups, my_groups + col * kBlockCells + v * kGroup + grp, tag, t);
+      if (slot_used<NS, MAX>(v) && col < ctx.replicas) put_cell(groups, my_groups + col * kBlockCells + v * kGroup + grp, tag, t);
     }
   }
   RSTAMP(2);
   RTRACE(ctx, epoch, 3, wall_clock64());
-  if (!gather_block<NS>(ctx, groups, my_groups + (blockIdx.x % ctx.replicas) * kBlockCells, tag, ngrp, val, &polls)) {
+  if (!gather_block<NS, MAX>(ctx, groups, my_groups + (blockIdx.x % ctx.replicas) * kBlockCells, tag, ngrp, val, &polls)) {
     *s_abort = 1;
     return false;
   }
-  fold_block(val);
+  fold_block<NS, MAX>(val);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int v = 4 * j + r;
-    if (slot_used<NS>(v) && col == kGroup - 1) sums[v] = val[j];
+    if (slot_used<NS, MAX>(v) && col == kGroup - 1) sums[v] = val[j];
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -528,9 +534,9 @@ template <int METHOD>
 __device__ __forceinline__ void reduce_pass(int kind, const double *acc, double mx, double *red, double *sums, long long *st_, long long &last_) {
   if constexpr (METHOD == 0) {
     switch (kind) {
-    case RQ_DIF_JAC: worker_reduce<SumLayout<kM>::DIF_JAC>(acc, mx, red, sums, st_, last_); break;
-    case RQ_DIF_TRIAL: worker_reduce<kTrialSums>(acc, mx, red, sums, st_, last_); break;
-    default: worker_reduce<1>(acc, mx, red, sums, st_, last_); break;
+    case RQ_DIF_JAC: worker_reduce<SumLayout<kM>::DIF_JAC, false>(acc, mx, red, sums, st_, last_); break;
+    case RQ_DIF_TRIAL: worker_reduce<kTrialSums, false>(acc, mx, red, sums, st_, last_); break;
+    default: worker_reduce<1, false>(acc, mx, red, sums, st_, last_); break;
     }
   } else {
     switch (kind) {
@@ -752,9 +758,9 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
        if (gridDim.x > 1) {      // ... and so is a single fit of <= 4096 samples: no exchange, no visibility hops
         if constexpr (METHOD == 0) {
           switch (kind) {
-          case RQ_DIF_JAC: alive = control_exchange<SumLayout<kM>::DIF_JAC>(ctx, epoch, sums, &s_abort, st_, last_); break;
-          case RQ_DIF_TRIAL: alive = control_exchange<kTrialSums>(ctx, epoch, sums, &s_abort, st_, last_); break;
-          default: alive = control_exchange<1>(ctx, epoch, sums, &s_abort, st_, last_); break;
+          case RQ_DIF_JAC: alive = control_exchange<SumLayout<kM>::DIF_JAC, false>(ctx, epoch, sums, &s_abort, st_, last_); break;
+          case RQ_DIF_TRIAL: alive = control_exchange<kTrialSums, false>(ctx, epoch, sums, &s_abort, st_, last_); break;
+          default: alive = control_exchange<1, false>(ctx, epoch, sums, &s_abort, st_, last_); break;
           }
         } else {
           switch (kind) {
