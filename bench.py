@@ -281,7 +281,7 @@ def main_batched(args):
         rows = torch.cat([p, info, ret.to(p.dtype)[:, None]], dim=1)
         if backend != "nccl":
             rows = rows.cpu()
-        return bdist.gather_results(rows, S)
+        return bdist.gather_results(rows, S, force=FORCE_COLL)
 
     for _ in range(args.warmup):
         one_step()

@@ -69,16 +69,24 @@ struct HostStage {
   double *d = nullptr;
   size_t cap = 0;
   int dev = -1;
+  // the block belongs to device `dev`: work queued THERE has to drain before it is freed, whatever device is current now
+  void release() {
+    if (!d) return;
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    if (cur != dev) (void)hipSetDevice(dev);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(d);
+    if (cur >= 0 && cur != dev) (void)hipSetDevice(cur);
+    d = nullptr;
+    cap = 0;
+  }
+  ~HostStage() { release(); }  // a host thread that ends gives its staging block back
   double *get(size_t count) {
     int cur = 0;
     if (hipGetDevice(&cur) != hipSuccess) return nullptr;
     if (d && cur == dev && cap >= count) return d;
-    if (d) {
-      (void)hipDeviceSynchronize();
-      (void)hipFree(d);
-      d = nullptr;
-      cap = 0;
-    }
+    release();
     const size_t want = count + count / 2 + 1024;
     if (hipMalloc(&d, want * sizeof(double)) != hipSuccess) {
       set_error("hipMalloc(%zu doubles) failed", want);
@@ -202,10 +210,7 @@ static int lu_noLapack(Real *A, Real *B, Real *x, int m, const char *who) {
       const Real t = std::fabs(a[(size_t)i * m + j]);
       if (t > big) big = t;
     }
-    if (big == Real(0.0)) {
-      fprintf(stderr, "Singular matrix A in %s()!\n", who);  // Axb_core.c:1203-1206
-      return 0;
-    }
+    if (big == Real(0.0)) return 0;  // silently, as the reference does (its message is commented out, Axb_core.c:1202-1208)
     scale[i] = Real(1.0) / big;
   }
   for (int j = 0; j < m; ++j) {

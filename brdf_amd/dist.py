@@ -20,17 +20,17 @@ def shard_range(total: int, rank: int, world: int) -> tuple[int, int]:
     return first, min(per, total - first)
 
 
-def gather_results(local: "torch.Tensor", total: int, group=None):
+def gather_results(local: "torch.Tensor", total: int, group=None, force: bool = False):
     """Gather per-rank result rows [count_r, K] to rank 0 as one [total, K] tensor (None on other ranks).
 
     Shards may be ragged (the last rank short/empty): every rank pads to ceil(total/world) rows, one
-    `dist.gather` moves them, rank 0 drops the padding.
+    `dist.gather` moves them, rank 0 drops the padding.  `force`: take the collective path on a ONE-rank communicator
+    too (bench.py's rehearsal of the RCCL calls on a one-GPU box); by default a single rank returns its rows untouched.
     """
     import torch
     import torch.distributed as dist
-    import os
-    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and os.environ.get("BRDF_BENCH_COLLECTIVES") != "1"):
-        return local  # (BRDF_BENCH_COLLECTIVES=1: bench.py's rehearsal of the collective on a one-rank communicator)
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
+        return local
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     per = -(-total // world)
     k = local.shape[1]

@@ -20,6 +20,12 @@ class FitResult:
     covar: np.ndarray | None = None
 
 
+def _require(cond: bool, what: str) -> None:
+    """Argument check that survives `python -O` (an `assert` would not): a bad shape, dtype or index must never reach a kernel."""
+    if not cond:
+        raise ValueError(what)
+
+
 def _dptr(a: np.ndarray | None):
     return None if a is None else a.ctypes.data_as(D)
 
@@ -28,7 +34,7 @@ def _f64(v, size):
     if v is None:
         return None
     a = np.ascontiguousarray(np.asarray(v, dtype=np.float64).reshape(-1))
-    assert a.size == size, f"expected {size} values, got {a.size}"
+    _require(a.size == size, f"expected {size} values, got {a.size}")
     return a
 
 
@@ -43,11 +49,11 @@ def fit_single(method: int, model: int, angles, x, p0, *, lb=None, ub=None, dscl
     Mirrors a dlevmar_dif / dlevmar_bc_dif call (levmar.h:112-127) with the samples already in HBM.
     """
     import torch
-    assert angles.is_cuda and x.is_cuda and angles.dtype == torch.float64 and x.dtype == torch.float64
+    _require(angles.is_cuda and x.is_cuda and angles.dtype == torch.float64 and x.dtype == torch.float64, "bad argument: " 'angles.is_cuda and x.is_cuda and angles.dtype == torch.float64 and x.dtype == torch.float64')
     angles = angles.contiguous()
     x = x.contiguous()
     n = x.numel()
-    assert angles.numel() == 3 * n
+    _require(angles.numel() == 3 * n, "bad argument: " 'angles.numel() == 3 * n')
     p = _f64(p0, 3).copy()
     info = np.zeros(10)
     covar = np.zeros(9) if want_covar else None
@@ -65,10 +71,10 @@ def fit_batch(method: int, model: int, angles, x, p0, *, lb=None, ub=None, itmax
     Returns (p [S,3], info [S,10], ret [S] int32) as CUDA tensors; asynchronous on the current stream.
     """
     import torch
-    assert angles.is_cuda and x.is_cuda and p0.is_cuda and angles.device == x.device == p0.device
-    assert angles.dtype == torch.float64 and x.dtype == torch.float64 and p0.dtype == torch.float64  # the kernels read raw doubles
+    _require(angles.is_cuda and x.is_cuda and p0.is_cuda and angles.device == x.device == p0.device, "bad argument: " 'angles.is_cuda and x.is_cuda and p0.is_cuda and angles.device == x.device == p0.device')
+    _require(angles.dtype == torch.float64 and x.dtype == torch.float64 and p0.dtype == torch.float64, "bad argument: " 'angles.dtype == torch.float64 and x.dtype == torch.float64 and p0.dtype == torch.float64')  # the kernels read raw doubles
     S, n = x.shape
-    assert tuple(angles.shape) == (S, 3, n) and tuple(p0.shape) == (S, 3)
+    _require(tuple(angles.shape) == (S, 3, n) and tuple(p0.shape) == (S, 3), "bad argument: " 'tuple(angles.shape) == (S, 3, n) and tuple(p0.shape) == (S, 3)')
     angles = angles.contiguous()
     x = x.contiguous()
     p = p0.contiguous()
@@ -87,7 +93,7 @@ def fit_batch(method: int, model: int, angles, x, p0, *, lb=None, ub=None, itmax
 def model_eval(model: int, angles, p):
     """hx = model(p; samples) on the device (kernel K1 alone).  angles: CUDA float64 [3,n]."""
     import torch
-    assert angles.is_cuda and angles.dtype == torch.float64 and angles.numel() % 3 == 0
+    _require(angles.is_cuda and angles.dtype == torch.float64 and angles.numel() % 3 == 0, "bad argument: " 'angles.is_cuda and angles.dtype == torch.float64 and angles.numel() % 3 == 0')
     angles = angles.contiguous()
     n = angles.numel() // 3
     hx = torch.empty(n, dtype=torch.float64, device=angles.device)
@@ -106,21 +112,32 @@ def led_table() -> np.ndarray:
     return out.reshape(16, 3)
 
 
-def cosines(vertices, faces, face_normals, leds, view_origin, *, surfels=None, rv_mode: int = 0):
+def _check_indices(idx, upper: int, what: str, lower: int = 0) -> None:
+    """Range check of an index tensor.  The two reductions synchronise with the device; callers that keep a stream busy
+    and vouch for their indices pass validate=False to the entry point instead."""
+    if idx.numel() == 0:
+        return
+    lo, hi = int(idx.min()), int(idx.max())
+    _require(lo >= lower and hi < upper, f"{what} (range [{lo}, {hi}], allowed [{lower}, {upper}))")
+
+
+def cosines(vertices, faces, face_normals, leds, view_origin, *, surfels=None, rv_mode: int = 0, validate: bool = True):
     """vectors -> cosines on the device (GetCosLN / GetCosNH / GetCosRV, brdfdata.cpp:799-943) for a batch of surfels.
     vertices [nv,3] float64, faces [nf,3] int32, face_normals [nf,3] float64: CUDA tensors; surfels: CUDA int32 [S]
     (face index per surfel) or None (surfel s = face s); leds [L,3], view_origin [3]: host.  Returns CUDA float64
     [S, 3, L] -- the batched fitter's `angles` layout."""
     import torch
     vertices, faces, face_normals = vertices.contiguous(), faces.contiguous(), face_normals.contiguous()
-    assert vertices.is_cuda and faces.is_cuda and face_normals.is_cuda
-    assert vertices.dtype == torch.float64 and face_normals.dtype == torch.float64 and faces.dtype == torch.int32
-    assert vertices.shape[-1] == 3 and faces.shape[-1] == 3 and tuple(face_normals.shape) == (faces.shape[0], 3)
-    assert faces.numel() == 0 or (int(faces.min()) >= 0 and int(faces.max()) < vertices.shape[0]), "face index outside the vertex array"
+    _require(vertices.is_cuda and faces.is_cuda and face_normals.is_cuda, "bad argument: " 'vertices.is_cuda and faces.is_cuda and face_normals.is_cuda')
+    _require(vertices.dtype == torch.float64 and face_normals.dtype == torch.float64 and faces.dtype == torch.int32, "bad argument: " 'vertices.dtype == torch.float64 and face_normals.dtype == torch.float64 and faces.dtype == torch.int32')
+    _require(vertices.shape[-1] == 3 and faces.shape[-1] == 3 and tuple(face_normals.shape) == (faces.shape[0], 3), "bad argument: " 'vertices.shape[-1] == 3 and faces.shape[-1] == 3 and tuple(face_normals.shape) == (faces.shape[0], 3)')
+    if validate:
+        _check_indices(faces, vertices.shape[0], "face index outside the vertex array")
     if surfels is not None:
         surfels = surfels.contiguous()
-        assert surfels.is_cuda and surfels.dtype == torch.int32
-        assert surfels.numel() == 0 or (int(surfels.min()) >= 0 and int(surfels.max()) < faces.shape[0]), "surfel index outside the face array"
+        _require(surfels.is_cuda and surfels.dtype == torch.int32, "bad argument: " 'surfels.is_cuda and surfels.dtype == torch.int32')
+        if validate:
+            _check_indices(surfels, faces.shape[0], "surfel index outside the face array")
     S = int(surfels.numel()) if surfels is not None else int(faces.shape[0])
     la = np.ascontiguousarray(leds, dtype=np.float64).reshape(-1, 3)
     L = la.shape[0]
@@ -136,25 +153,28 @@ def cosines(vertices, faces, face_normals, leds, view_origin, *, surfels=None, r
 
 
 def fit_capture(model: int, images, pixel_map, vertices, faces, face_normals, leds, view_origin, *, rv_mode: int = 0,
-                p0=(0.5, 1.0, 1.0), lb=(0.0, 0.0, 0.0), ub=(100.0, 100.0, 100.0), itmax: int = 100, opts=None, brdf_surfaces=None):
+                p0=(0.5, 1.0, 1.0), lb=(0.0, 0.0, 0.0), ub=(100.0, 100.0, 100.0), itmax: int = 100, opts=None, brdf_surfaces=None,
+                validate: bool = True):
     """The pixel loop of CBRDFdata::CalcBRDFEquation (brdfdata.cpp:1188-1227) on the device.  images: CUDA uint8
     [L,H,W,3] (BGR), pixel_map: CUDA int32 [H,W] (face index or -1), mesh as in cosines().  Returns (brdf_surfaces
     CUDA float64 [nf,3,3] = {kd,ks,n} per face and channel, avg[3], number of pixels that carried a face)."""
     import torch
     images, pixel_map = images.contiguous(), pixel_map.contiguous()
     vertices, faces, face_normals = vertices.contiguous(), faces.contiguous(), face_normals.contiguous()
-    assert images.is_cuda and pixel_map.is_cuda and vertices.is_cuda and faces.is_cuda and face_normals.is_cuda
-    assert images.dtype == torch.uint8 and pixel_map.dtype == torch.int32 and faces.dtype == torch.int32
-    assert vertices.dtype == torch.float64 and face_normals.dtype == torch.float64
-    assert images.dim() == 4 and images.shape[3] == 3 and tuple(pixel_map.shape) == tuple(images.shape[1:3])  # [L,H,W,3] BGR, [H,W]
-    assert tuple(face_normals.shape) == (faces.shape[0], 3) and vertices.shape[-1] == 3
-    assert int(pixel_map.max()) < faces.shape[0], "pixel map names a face that does not exist"
+    _require(images.is_cuda and pixel_map.is_cuda and vertices.is_cuda and faces.is_cuda and face_normals.is_cuda, "bad argument: " 'images.is_cuda and pixel_map.is_cuda and vertices.is_cuda and faces.is_cuda and face_normals.is_cuda')
+    _require(images.dtype == torch.uint8 and pixel_map.dtype == torch.int32 and faces.dtype == torch.int32, "bad argument: " 'images.dtype == torch.uint8 and pixel_map.dtype == torch.int32 and faces.dtype == torch.int32')
+    _require(vertices.dtype == torch.float64 and face_normals.dtype == torch.float64, "bad argument: " 'vertices.dtype == torch.float64 and face_normals.dtype == torch.float64')
+    _require(images.dim() == 4 and images.shape[3] == 3 and tuple(pixel_map.shape) == tuple(images.shape[1:3]), "bad argument: " 'images.dim() == 4 and images.shape[3] == 3 and tuple(pixel_map.shape) == tuple(images.shape[1:3])')  # [L,H,W,3] BGR, [H,W]
+    _require(tuple(face_normals.shape) == (faces.shape[0], 3) and vertices.shape[-1] == 3, "bad argument: " 'tuple(face_normals.shape) == (faces.shape[0], 3) and vertices.shape[-1] == 3')
+    if validate:  # (-1 = no face under the pixel)
+        _check_indices(pixel_map, faces.shape[0], "pixel map names a face that does not exist", lower=-1)
+        _check_indices(faces, vertices.shape[0], "face index outside the vertex array")
     L, H, W = int(images.shape[0]), int(images.shape[1]), int(images.shape[2])
     nf = int(faces.shape[0])
     if brdf_surfaces is None:
         brdf_surfaces = torch.zeros((nf, 3, 3), dtype=torch.float64, device=images.device)
     la = np.ascontiguousarray(leds, dtype=np.float64).reshape(-1, 3)
-    assert la.shape[0] == L
+    _require(la.shape[0] == L, "bad argument: " 'la.shape[0] == L')
     va, pa, lba, uba = _f64(view_origin, 3), _f64(p0, 3), _f64(lb, 3), _f64(ub, 3)
     oa = _f64(opts, 5) if opts is not None else None
     avg = np.zeros(3)
@@ -171,23 +191,25 @@ def fit_capture(model: int, images, pixel_map, vertices, faces, face_normals, le
 
 def fit_capture_single(model: int, images, pixel_map, vertices, faces, face_normals, leds, view_origin, *, rv_mode: int = 0,
                        p0=(0.0, 0.0, 0.0), lb=(0.0, 0.0, 0.0), ub=(100.0, 100.0, 100.0), itmax: int = 2000,
-                       opts=(1e-3, 1e-15, 1e-10, 1e-50, 1.0)):
+                       opts=(1e-3, 1e-15, 1e-10, 1e-50, 1.0), validate: bool = True):
     """CalcBRDFEquation_SingleBRDF (brdfdata.cpp:1138-1186) on the device: one {kd, ks, n} per colour channel for the
     whole object.  Defaults are the reference's call-site values (brdfdata.cpp:1002, :1046-1056).  Returns
     (single_brdf [3,3], info [3,10], faces used)."""
     import torch
     images, pixel_map = images.contiguous(), pixel_map.contiguous()
     vertices, faces, face_normals = vertices.contiguous(), faces.contiguous(), face_normals.contiguous()
-    assert images.is_cuda and pixel_map.is_cuda and vertices.is_cuda and faces.is_cuda and face_normals.is_cuda
-    assert images.dtype == torch.uint8 and pixel_map.dtype == torch.int32 and faces.dtype == torch.int32
-    assert vertices.dtype == torch.float64 and face_normals.dtype == torch.float64
-    assert images.dim() == 4 and images.shape[3] == 3 and tuple(pixel_map.shape) == tuple(images.shape[1:3])  # [L,H,W,3] BGR, [H,W]
-    assert tuple(face_normals.shape) == (faces.shape[0], 3) and vertices.shape[-1] == 3
-    assert int(pixel_map.max()) < faces.shape[0], "pixel map names a face that does not exist"
+    _require(images.is_cuda and pixel_map.is_cuda and vertices.is_cuda and faces.is_cuda and face_normals.is_cuda, "bad argument: " 'images.is_cuda and pixel_map.is_cuda and vertices.is_cuda and faces.is_cuda and face_normals.is_cuda')
+    _require(images.dtype == torch.uint8 and pixel_map.dtype == torch.int32 and faces.dtype == torch.int32, "bad argument: " 'images.dtype == torch.uint8 and pixel_map.dtype == torch.int32 and faces.dtype == torch.int32')
+    _require(vertices.dtype == torch.float64 and face_normals.dtype == torch.float64, "bad argument: " 'vertices.dtype == torch.float64 and face_normals.dtype == torch.float64')
+    _require(images.dim() == 4 and images.shape[3] == 3 and tuple(pixel_map.shape) == tuple(images.shape[1:3]), "bad argument: " 'images.dim() == 4 and images.shape[3] == 3 and tuple(pixel_map.shape) == tuple(images.shape[1:3])')  # [L,H,W,3] BGR, [H,W]
+    _require(tuple(face_normals.shape) == (faces.shape[0], 3) and vertices.shape[-1] == 3, "bad argument: " 'tuple(face_normals.shape) == (faces.shape[0], 3) and vertices.shape[-1] == 3')
+    if validate:  # (-1 = no face under the pixel)
+        _check_indices(pixel_map, faces.shape[0], "pixel map names a face that does not exist", lower=-1)
+        _check_indices(faces, vertices.shape[0], "face index outside the vertex array")
     L, H, W = int(images.shape[0]), int(images.shape[1]), int(images.shape[2])
     nf = int(faces.shape[0])
     la = np.ascontiguousarray(leds, dtype=np.float64).reshape(-1, 3)
-    assert la.shape[0] == L
+    _require(la.shape[0] == L, "bad argument: " 'la.shape[0] == L')
     va, pa, lba, uba, oa = _f64(view_origin, 3), _f64(p0, 3), _f64(lb, 3), _f64(ub, 3), _f64(opts, 5)
     out, info = np.zeros(9), np.zeros(30)
     nfu = C.c_longlong(0)

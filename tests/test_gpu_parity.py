@@ -493,6 +493,25 @@ def test_resident_and_launch_chain_regimes(gpu, monkeypatch):
                 assert (st["launches"] == 1) == (env == "1"), st
 
 
+@pytest.mark.parametrize("method,n,models", [(0, 262145, (2, 1)), (1, 262145, (2, 1)), (2, 262145, (2,)), (3, 262145, (2,)),
+                                             (0, 263000, (2, 1)), (1, 263000, (2,)), (2, 263000, (2,)), (3, 263000, (2,)),
+                                             (0, 523009, (2,)), (1, 523009, (2,))])
+def test_resident_regime_with_a_short_last_workgroup(gpu, method, n, models):
+    """A single fit spread over all CUs deals tiles of ceil(n / #CUs) samples, so the LAST workgroup holds up to #CUs - 1
+    samples fewer than the others: its slot nk - 2 can be partly empty and its slot nk - 1 entirely (n = 262,145 on 256
+    CUs: tile 1025, nk 3, last workgroup 770 samples).  Lanes without a sample must contribute nothing in EVERY slot (a
+    round-2 kernel masked the last slot only and summed sample `begin` up to 255 times for a quarter of the sizes in
+    (261120, 2^20]).  All four entry points, Ward and Blinn-Phong, against the oracle at the usual 1e-5 / 1e-8."""
+    torch, brdf_amd, dev = gpu
+    for model in models:
+        lb, ub = synth.bounds(model) if method == 2 else (synth.LB, synth.UB)
+        angles, x, _ = synth.make_single(model, n)
+        _, p_ref, info_ref = L.brdf_fit("orc", method, model, angles, x, synth.P0[model], synth.ITMAX, synth.OPTS, lb, ub)
+        res = _dev_fit(gpu, method, model, angles, x, lb=lb, ub=ub)
+        assert brdf_amd.last_fit_stats()["launches"] == 1  # the resident regime did the work
+        _check(res, p_ref, info_ref)
+
+
 def test_resident_regime_falls_back_when_a_workgroup_never_arrives(gpu, monkeypatch, capfd):
     """every spin of the resident kernel is bounded: with one workgroup withholding its partial row (test hook) the
     launch drains, reports `abort`, and the host redoes the fit with the launch chain -- same answer, no hang"""
