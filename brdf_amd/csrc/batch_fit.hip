@@ -646,6 +646,15 @@ bool lane_path_enabled() {
 }  // namespace
 
 // BRDF_HIP_BATCH_BIG=0: the symmetric 512 x 8 geometry of this file instead of the control-wave kernel for 1024 < n <= 4096
+// BRDF_HIP_BATCH_DIF_CHAIN=k: the eight-wave batched dlevmar_dif kernel's trial points per sweep in a chain of rejections
+// (default: the single fits' setting, BRDF_HIP_DIF_CHAIN)
+static int batch_dif_chain() {
+  const char *e = getenv("BRDF_HIP_BATCH_DIF_CHAIN");
+  if (!e) return dif_chain_candidates();
+  const int k = atoi(e);
+  return k < 1 ? 1 : (k > kMaxCand ? kMaxCand : k);
+}
+
 static bool big_path_enabled() {
   const char *e = getenv("BRDF_HIP_BATCH_BIG");
   return !(e && e[0] == '0');
@@ -673,6 +682,8 @@ int batch_fit_launches(const BatchFitArgs &a, const Geometry &g, int *flags, int
   // projected-gradient candidates per sweep: pays where the LM step dominates a pass; the 512 x 8 geometry would
   // spill its register-resident samples with 8 unrolled candidates (measured 2.4x slower), so it stays at one
   c.multi = (g.threads == 512) ? 1 : pg_candidates();
+  c.chain = 1;     // (only the eight-wave kernel compiles the chains in)
+  c.spec_jac = 0;  // batched fits are bound by arithmetic: a Jacobian pass that is not used costs three evaluations
   for (int i = 0; i < 5; ++i) c.opts[i] = a.opts ? a.opts[i] : 0.0;
   for (int i = 0; i < kM; ++i) {
     c.lb[i] = a.lb ? a.lb[i] : 0.0;
@@ -688,6 +699,7 @@ int batch_fit_launches(const BatchFitArgs &a, const Geometry &g, int *flags, int
   }
   if (g.threads == 512 && (big_path_enabled() || method == 2 || c.analytic)) {  // 1024 < n <= 4096: eight waves per fit (resident_fit.hip)
     c.multi = pg_candidates();
+    c.chain = batch_dif_chain();
     if (!fast) HIP_OK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(flags), kNeedsExact, (size_t)a.S, a.stream));
     return resident_batch_enqueue(a.model, method, fast, c, a.stream);
   }

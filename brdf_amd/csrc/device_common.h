@@ -72,15 +72,16 @@ __device__ __forceinline__ double row_reduce_to_last(double v) {
   return v;
 }
 
-// Workgroup reduction of NS sums and one max.  The order is a pure function of (THREADS, NS): results are
+// Workgroup reduction of NS sums and one max.  The order is a pure function of THREADS: results are
 // reproducible run to run.  out[0..NS) receive the sums, out[kSums] the max; visible to all threads on return.
 //
-//  NS == 1 (the common evaluation pass): DPP tree inside each wave, the last lane of every wave parks its
-//           value in LDS, two threads fold the per-wave values in wave order.
-//  NS  > 1 (Jacobian / Broyden passes, 9..13 sums): a DPP chain per value per wave would serialise ~14 dependent
-//           chains in every wave, so the values are transposed through LDS instead: every thread parks its NS+1
-//           values as buf[slot][thread]; then wave w owns slots {w, w+NW, ..}: each lane adds THREADS/64 entries
-//           of the slot in a fixed order and ONE DPP tree per slot finishes it.
+// A DPP chain per value per wave would serialise ~14 dependent chains in every wave (Jacobian / Broyden passes reduce 9..13
+// sums), so the values are transposed through LDS instead: every thread parks its NS+1 values as buf[slot][thread]; then
+// wave w owns slots {w, w+NW, ..}: each lane adds THREADS/64 entries of the slot in a fixed order and ONE DPP tree per slot
+// finishes it.  The order in which one slot is summed does NOT depend on NS (an evaluation pass used to have a path of its
+// own: per-wave trees first): the machines compare sums of squares that come from passes of different kinds -- a trial point
+// evaluated by an evaluation pass, by a multi-candidate pass or by the Jacobian pass at that point (lm_machine.h: spec_jac)
+// -- and with one order those are the same bits, as they are in the reference, where one function forms them all.
 template <int THREADS>
 constexpr int reduce_buf_doubles() { return kSlots * THREADS; }
 
@@ -89,28 +90,7 @@ __device__ __forceinline__ void block_reduce(const double *acc, double mx, doubl
   constexpr int NW = THREADS / kWave;
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
-  if constexpr (NS == 1) {
-    const double v = wave_reduce_to_last<OpSum>(acc[0]);
-    const double m = wave_reduce_to_last<OpMax>(mx);
-    if (lane == kWave - 1) {
-      buf[wave] = v;
-      buf[NW + wave] = m;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      double s = buf[0];
-#pragma unroll
-      for (int w = 1; w < NW; ++w) s += buf[w];
-      out[0] = s;
-    } else if (threadIdx.x == kWave) {  // a lane of the second wave when there is one (any thread would do)
-      double s = buf[NW];
-#pragma unroll
-      for (int w = 1; w < NW; ++w) s = fmax(s, buf[NW + w]);
-      out[kSums] = s;
-    }
-    if (NW == 1 && threadIdx.x == 0) out[kSums] = buf[NW];
-    __syncthreads();
-  } else {
+  {
 #pragma unroll
     for (int k = 0; k < NS; ++k) buf[k * THREADS + threadIdx.x] = acc[k];
     buf[NS * THREADS + threadIdx.x] = mx;

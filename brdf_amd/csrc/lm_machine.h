@@ -315,7 +315,7 @@ LM_HD FitOptionsT<Real> make_options(const Real *opts) {
 // =================================================================================================
 template <int M, class Real = double>
 struct DifMachine {
-  enum Phase : int { D_INIT_EVAL = 1, D_ITER_TOP, D_AFTER_JAC, D_GRADIENT, D_SOLVE, D_AFTER_TRIAL, D_AFTER_UPDATE, D_DECIDE, D_REJECT, D_FINISH, D_DONE };
+  enum Phase : int { D_INIT_EVAL = 1, D_ITER_TOP, D_AFTER_JAC, D_GRADIENT, D_SOLVE, D_AFTER_TRIAL, D_AFTER_UPDATE, D_DECIDE, D_REJECT, D_AFTER_MULTI, D_FINISH, D_DONE };
   // Cold: configuration and results, touched at start/finish only.  Hot: everything an LM step reads or
   // writes.  (Measured on gfx950: running the step on a register copy of Hot makes hipcc spill to scratch
   // and is slower than stepping in place in LDS, so step() works in place.)
@@ -329,18 +329,28 @@ struct DifMachine {
                       // 0: trial pass, decision, then an update pass (RQ_DIF_UPDATE), the plain restatement of
                       //    lm_core.c:742-790: the host-callback path (generic_fit.hip), where hx and J are whole
                       //    vectors in HBM, and the host harness (tests/cpp/host_machine.cpp; bit-exact, like 1)
+    int multi;        // > 1: a chain of rejections is evaluated up to `multi` trial points at a time.  While no step has been
+                      //   taken since the last fresh Jacobian (updp == 0) a rejected trial changes nothing but the damping
+                      //   (lm_core.c:797-806: mu *= nu, nu *= 2; no Broyden update, :757), so the NEXT trial points -- the
+                      //   solutions of (J^T J + mu_j I) dp = J^T e for mu_j = mu nu, mu nu 2nu, ... -- are known before the current
+                      //   one has been judged.  Near the end of a fit (every step rejected until ||Dp|| falls under eps2) that is
+                      //   most of the passes.  RQ_EVAL_MULTI evaluates them in one sweep; they are judged in the reference's order,
+                      //   only the judged ones are counted, and a candidate that reduces the error is evaluated again by the plain
+                      //   trial pass (which forms the Broyden sums): p, info[] and the trajectory are those of one trial at a time.
     Real info[kInfoSz], covar[M * M];
     int ret;
   };
   struct Core {  // everything an LM step reads or writes, except the request it leaves
     int phase, k, stop, nu, nfev, njap, nlss, updjac, updp, newjac;
     int sel_hx, sel_j, accepted;
+    int chain, single, mcnt;  // multi: rejections without an update in a row; next solve issues a plain trial; candidates out
     Real p[M], mu, p_e2, jte_inf, p_l2, dp_l2, pdp_e2;
     Real jtj[M * M], jte[M], dp[M];
   };
   struct Cool {  // the less busy half of the state (see Hot)
     Real init_e2, diag[M], pdp[M];
     Real spec_jtj[M * M], spec_jte[M];  // normal equations of the Broyden-updated J, adopted lazily
+    Real ml2[kMaxCand];                  // multi: ||Dp||^2 of the candidates out (info[3] is the last one judged)
   };
   // Core + Cool + the request.  run() takes them separately, so that a kernel can step on a REGISTER copy of Core
   // while the rest stays in LDS (resident_fit.hip: the sweeping waves read the request there; with Cool in registers as
@@ -365,15 +375,21 @@ struct DifMachine {
     h.sel_hx = lm_uniform(h.sel_hx);
     h.sel_j = lm_uniform(h.sel_j);
     h.accepted = lm_uniform(h.accepted);
+    h.chain = lm_uniform(h.chain);
+    h.single = lm_uniform(h.single);
+    h.mcnt = lm_uniform(h.mcnt);
   }
   Cold c;
   Hot h;
 
-  LM_HD void start(const Real *p0, int n_, int itmax_, const Real *opts, int want_covar_, int speculative_ = 1) {
+  LM_HD void start(const Real *p0, int n_, int itmax_, const Real *opts, int want_covar_, int speculative_ = 1, int multi_ = 1) {
     Request<M, Real> &req = h.req;
     Cool &cool = h.cool;
     c.o = make_options(opts);
     c.speculative = speculative_;
+    c.multi = (multi_ < 1 || !speculative_) ? 1 : ((multi_ > kMaxCand) ? kMaxCand : multi_);
+    h.chain = h.single = h.mcnt = 0;
+    for (int j = 0; j < kMaxCand; ++j) cool.ml2[j] = Real(0.0);
     h.accepted = 0;
     c.itmax = itmax_;
     c.n = n_;
@@ -416,6 +432,7 @@ struct DifMachine {
     req.aux = 0;
     req.dp_l2 = Real(0.0);
     req.scal = Real(1.0);
+    req.nk = 0;
     for (int i = 0; i < M; ++i) req.p[i] = req.d[i] = req.q[i] = req.dp[i] = Real(0.0);
   }
 
@@ -430,10 +447,11 @@ struct DifMachine {
   }
 
   // ONE_LANE: the caller guarantees that exactly one lane of the wave executes this step (see lm_uniform)
-  template <bool ONE_LANE = false>
-  LM_HD void step(const Real *s, Real maxabs) { run<ONE_LANE>(c, h, h.cool, h.req, s, maxabs); }
+  // MULTI: compiles the multi-candidate rejection chains in (Cold::multi > 1 turns them on)
+  template <bool ONE_LANE = false, bool MULTI = false>
+  LM_HD void step(const Real *s, Real maxabs) { run<ONE_LANE, MULTI>(c, h, h.cool, h.req, s, maxabs); }
 
-  template <bool ONE_LANE>
+  template <bool ONE_LANE, bool MULTI = false>
   static LM_HD void run(Cold &c, Core &h, Cool &cool, Request<M, Real> &req, const Real *s, Real /*maxabs*/) {
     int ph = ONE_LANE ? lm_uniform(h.phase) : h.phase;  // scalar register: phase transitions become scalar jumps
     LM_STAMP(0);
@@ -472,6 +490,7 @@ struct DifMachine {
         }
         const Real dF = h.p_e2 - h.pdp_e2;
         const bool updated = (h.updp || dF > 0);
+        if (MULTI) h.chain = updated ? 0 : h.chain + 1;  // (not updated => dF <= 0 => rejected below)
         Real dL = Real(0.0);
         for (int i = 0; i < M; ++i) dL += h.dp[i] * (h.mu * h.dp[i] + h.jte[i]);
         h.accepted = (dL > Real(0.0) && dF > Real(0.0)) ? 1 : 0;
@@ -513,6 +532,42 @@ struct DifMachine {
         unpack_lower<M>(s, cool.spec_jtj);
         for (int i = 0; i < M; ++i) cool.spec_jte[i] = s[SumLayout<M>::NL + i];
         ph = D_DECIDE;
+        break;
+      } LM_PHASE_END
+
+      if constexpr (MULTI)
+      LM_PHASE(D_AFTER_MULTI) {  // judge the candidates of one sweep in the reference's order: each is one iteration of
+                                 // lm_core.c:566-807 that ends in the rejection branch without a Broyden update
+        const int cnt = h.mcnt;
+        int next = D_ITER_TOP;
+        for (int j = 0; j < kMaxCand; ++j) {
+          if (j >= cnt || !(h.k < c.itmax)) break;  // (the iteration count ends the loop at its top, lm_core.c:566)
+          const Real e2 = s[j];
+          if (lm_finite(e2) && h.p_e2 - e2 > Real(0.0)) {  // dF > 0: Broyden update, maybe an accepted step -- the plain
+            h.single = 1;                                   // trial pass evaluates this candidate again and forms its sums
+            break;
+          }
+          ++h.nlss;  // the solve that produced this candidate (lm_core.c:691) ...
+          ++h.nfev;  // ... and its evaluation (lm_core.c:738)
+          h.pdp_e2 = e2;
+          h.dp_l2 = cool.ml2[j];
+          if (!lm_finite(e2)) {  // lm_core.c:749
+            h.stop = 7;
+            next = D_FINISH;
+            break;
+          }
+          ++h.chain;
+          h.mu *= h.nu;  // lm_core.c:797-806
+          const int nu2 = (int)((unsigned)h.nu << 1);
+          if (nu2 <= h.nu) {
+            h.stop = 5;
+            next = D_FINISH;
+            break;
+          }
+          h.nu = nu2;
+          ++h.k;
+        }
+        ph = next;
         break;
       } LM_PHASE_END
 
@@ -568,6 +623,7 @@ struct DifMachine {
           h.updjac = 0;
           h.updp = 0;
           h.newjac = 1;
+          if (MULTI) h.chain = 0;
           ph = D_AFTER_JAC;
           { h.phase = ph; return; }
         }
@@ -601,6 +657,48 @@ struct DifMachine {
             if (cool.diag[i] > t) t = cool.diag[i];
           h.mu = c.o.tau * t;
         }
+        if (MULTI && c.multi > 1 && h.updp == 0 && h.chain >= 1 && !h.single) {
+          // no step taken since the fresh Jacobian and the last trial was rejected without an update: if this trial is
+          // rejected too, the next one differs by its damping only.  Form the trial points of the next rejections as the
+          // loop would (same solves, same tests), stop in front of the first one the loop would not evaluate.
+          Real A[M * M], b[M], pc[M];
+          for (int i = 0; i < M * M; ++i) A[i] = h.jtj[i];
+          for (int i = 0; i < M; ++i) {
+            b[i] = h.jte[i];
+            pc[i] = h.p[i];
+          }
+          Real mu = h.mu;
+          int nu = h.nu, kk = h.k, cnt = 0;
+          const Real pl2 = h.p_l2;
+          for (int j = 0; j < kMaxCand; ++j) {
+            if (j >= c.multi || !(kk < c.itmax)) break;
+            Real dpj[M];
+            for (int i = 0; i < M; ++i) A[i * M + i] = cool.diag[i] + mu;
+            if (!lu_solve<M>(A, b, dpj)) break;
+            Real l2 = Real(0.0);
+            for (int i = 0; i < M; ++i) {
+              req.pk[j][i] = pc[i] + dpj[i];
+              l2 += dpj[i] * dpj[i];
+            }
+            if (l2 <= c.o.eps2sq * pl2 || l2 >= (pl2 + c.o.eps2) / (Real(kEpsilon) * Real(kEpsilon))) break;
+            cool.ml2[j] = l2;
+            ++cnt;
+            mu *= nu;
+            const int nu2 = (int)((unsigned)nu << 1);
+            if (nu2 <= nu) break;
+            nu = nu2;
+            ++kk;
+          }
+          if (cnt >= 2) {
+            h.mcnt = cnt;
+            req.kind = RQ_EVAL_MULTI;
+            req.nk = cnt;
+            req.scal = Real(1.0);
+            ph = D_AFTER_MULTI;
+            { h.phase = ph; return; }
+          }
+        }
+        if (MULTI) h.single = 0;
         for (int i = 0; i < M; ++i) h.jtj[i * M + i] += h.mu;
         const int solved = lu_solve<M>(h.jtj, h.jte, h.dp);
         LM_STAMP(3);
@@ -689,12 +787,21 @@ struct BcMachine {
                        // next points are known before the current one has been judged, so K of them share a sweep.
                        // Candidates are judged in the reference's order and only the judged ones count in nfev:
                        // the trajectory and info[] are exactly those of the one-at-a-time search.
+    int spec_jac;      // 1: a candidate that becomes p when it is taken (the LM trial point, a line-search point, the start)
+                       // is evaluated by a JACOBIAN pass at that point (RQ_JAC: its sum of squares is the evaluation's,
+                       // bit for bit; its J^T J / J^T e are kept).  When the candidate is taken, the Jacobian pass the next
+                       // iteration opens with (lmbc_core.c:555-561 at the same point, same steps) is already done: one pass
+                       // per accepted iteration instead of two.  Where a pass costs its latency, not its arithmetic (one fit
+                       // spread over the chip), that is the gain; the batched kernels, bound by arithmetic, leave it off.
+                       // Counters (nfev, njev) advance exactly as without it: info[] and the trajectory do not change.
+                       // (step<..., SPECJ = true> only; never with dscl, whose scaled points do not round-trip.)
     Real p_start[M];
     Real info[kInfoSz], covar[M * M];
     int ret;
   };
   struct Core {  // everything an LM step reads or writes, except the request it leaves
     int phase, k, stop, nu, nfev, njev, nlss, gprev;
+    int spec_state;  // spec_jac: 0 nothing kept, 1 cool.sj holds the Jacobian sums at pdp, 2 ... at p, 3 B_AFTER_JAC reads them
     Real p[M], mu, p_e2, jte_inf, p_l2, dp_l2, pdp_e2;
     Real jtj[M * M], jte[M], dp[M], pdp[M];
     Real t, gdp;
@@ -703,6 +810,7 @@ struct BcMachine {
   };
   struct Cool {  // the less busy half of the state (see Hot)
     Real init_e2, keep_max, diag[M], t0;
+    Real sj[SumLayout<M>::JAC];  // spec_jac: the sums of the Jacobian pass that evaluated the candidate
     // line-search locals (lmbc_core.c:218-225)
     Real ls_f0, ls_lambda, ls_plmbda, ls_pfpls, ls_tlmbda, ls_rmnlmb, ls_slp;
   };
@@ -724,6 +832,7 @@ struct BcMachine {
     h.njev = lm_uniform(h.njev);
     h.nlss = lm_uniform(h.nlss);
     h.gprev = lm_uniform(h.gprev);
+    h.spec_state = lm_uniform(h.spec_state);
     h.ls_first = lm_uniform(h.ls_first);
     h.ls_left = lm_uniform(h.ls_left);
     h.pg_n = lm_uniform(h.pg_n);
@@ -775,9 +884,19 @@ struct BcMachine {
     }
     ++h.nfev;
   }
+  // the same evaluation, asked for as a Jacobian pass at v (Cold::spec_jac); v is unscaled (never used with dscl)
+  static LM_HD void request_eval_jac(const Cold &c, Core &h, Request<M, Real> &req, const Real *v) {
+    req.kind = RQ_JAC;
+    req.scal = Real(1.0);
+    req.central = !c.o.forward;
+    for (int i = 0; i < M; ++i) req.p[i] = v[i];
+    fd_steps<M>(req.p, c.o.delta, req.d);
+    ++h.nfev;
+    h.spec_state = 1;
+  }
 
   LM_HD void start(const Real *p0, int n_, const Real *lb_, const Real *ub_, const Real *dscl_,
-                   int itmax_, const Real *opts, int want_covar_, int multi_ = 1) {
+                   int itmax_, const Real *opts, int want_covar_, int multi_ = 1, int spec_jac_ = 0) {
     Request<M, Real> &req = h.req;
     Cool &cool = h.cool;
     c.multi = (multi_ < 1) ? 1 : ((multi_ > kMaxCand) ? kMaxCand : multi_);
@@ -794,6 +913,8 @@ struct BcMachine {
     c.has_ub = ub_ != nullptr;
     c.has_dscl = dscl_ != nullptr;
     c.analytic_jac = 0;
+    c.spec_jac = (spec_jac_ && !c.has_dscl) ? 1 : 0;
+    h.spec_state = 0;
     h.k = 0;
     h.stop = 0;
     h.nu = 2;
@@ -816,6 +937,7 @@ struct BcMachine {
       h.jte[i] = cool.diag[i] = h.dp[i] = h.pdp[i] = Real(0.0);
     }
     for (int i = 0; i < M * M; ++i) h.jtj[i] = c.covar[i] = Real(0.0);
+    for (int i = 0; i < SumLayout<M>::JAC; ++i) cool.sj[i] = Real(0.0);
     for (int i = 0; i < kInfoSz; ++i) c.info[i] = Real(0.0);
     clear_req(h, req);
     h.phase = B_DONE;
@@ -842,22 +964,40 @@ struct BcMachine {
     clear_req(h, req);
     req.kind = RQ_EVAL;  // the first evaluation is at the unscaled projected start, lmbc_core.c:523
     for (int i = 0; i < M; ++i) req.p[i] = h.p[i];
+    if (c.spec_jac) {  // ... as the Jacobian pass the first iteration opens with (same point: no dscl here)
+      request_eval_jac(c, h, req, h.p);
+      h.nfev = 0;
+    }
     h.phase = B_INIT_EVAL;
   }
+  // (the analytic-Jacobian flag is set by the callers after start(): the kind of the FIRST request does not depend on it)
 
+  template <bool SPECJ = false>
   static LM_HD void accept_trial(Core &h) {  // p <- pdp, ||e||^2 <- trial value
     for (int i = 0; i < M; ++i) h.p[i] = h.pdp[i];
     h.p_e2 = h.pdp_e2;
+    if (SPECJ) h.spec_state = (h.spec_state == 1) ? 2 : 0;  // the Jacobian sums kept for pdp are now those of p
+  }
+  // the sum of squares a candidate's pass returned: slot 0 of an evaluation pass, the last slot of a Jacobian pass (whose
+  // other sums are kept for the iteration that may open at this point)
+  template <bool SPECJ>
+  static LM_HD Real candidate_e2(Core &h, Cool &cool, const Real *s) {
+    if (SPECJ && h.spec_state == 1) {
+      for (int i = 0; i < SumLayout<M>::JAC; ++i) cool.sj[i] = s[i];
+      return s[SumLayout<M>::JAC - 1];
+    }
+    return s[0];
   }
 
   // MULTI = false compiles the multi-candidate projected-gradient machinery out (callers that start with multi = 1).
   // GATED: the expensive phases -- everything behind a Jacobian pass (B_AFTER_JAC, B_SOLVE: the 3x3 LU), the line-search
   // prologue (pow, square roots, divisions) and B_FINISH -- only run when `heavy` is set; otherwise the step stops in front
   // of them with RQ_YIELD.  Pure scheduling: a machine's trajectory does not depend on when its phases run.
-  template <bool ONE_LANE = false, bool MULTI = true, bool GATED = false>
-  LM_HD void step(const Real *s, Real maxabs, bool heavy = true) { run<ONE_LANE, MULTI, GATED>(c, h, h.cool, h.req, s, maxabs, heavy); }
+  // SPECJ: compiles the speculative Jacobian passes in (Cold::spec_jac turns them on)
+  template <bool ONE_LANE = false, bool MULTI = true, bool GATED = false, bool SPECJ = false>
+  LM_HD void step(const Real *s, Real maxabs, bool heavy = true) { run<ONE_LANE, MULTI, GATED, SPECJ>(c, h, h.cool, h.req, s, maxabs, heavy); }
 
-  template <bool ONE_LANE, bool MULTI, bool GATED>
+  template <bool ONE_LANE, bool MULTI, bool GATED, bool SPECJ = false>
   static LM_HD void run(Cold &c, Core &h, Cool &cool, Request<M, Real> &req, const Real *s, Real maxabs, bool heavy) {
     constexpr Real alpha = Real(1e-4), beta = Real(0.9), gamma = Real(0.99995), rho = Real(1e-8), tming = Real(1e-18), tini = Real(1.0);
     int ph = ONE_LANE ? lm_uniform(h.phase) : h.phase;  // scalar register: phase transitions become scalar jumps
@@ -876,7 +1016,8 @@ struct BcMachine {
       }
       LM_PHASE(B_INIT_EVAL) {  // lmbc_core.c:523-540
         h.nfev = 1;
-        h.p_e2 = s[0];
+        h.p_e2 = candidate_e2<SPECJ>(h, cool, s);
+        if (SPECJ && h.spec_state == 1) h.spec_state = 2;  // the start IS p
         cool.init_e2 = h.p_e2;
         if (!lm_finite(h.p_e2)) h.stop = 7;
         if (c.has_dscl)
@@ -892,8 +1033,11 @@ struct BcMachine {
       LM_GATE(B_AFTER_JAC)
       if (!GATED || heavy)
       LM_PHASE(B_AFTER_JAC) {
-        unpack_lower<M>(s, h.jtj);
-        for (int i = 0; i < M; ++i) h.jte[i] = s[SumLayout<M>::NL + i];
+        const Real *sv = s;
+        if (SPECJ && h.spec_state == 3) sv = cool.sj;  // the pass that evaluated this point as a candidate left them
+        if (SPECJ) h.spec_state = 0;
+        unpack_lower<M>(sv, h.jtj);
+        for (int i = 0; i < M; ++i) h.jte[i] = sv[SumLayout<M>::NL + i];
         if (c.has_dscl) {  // J <- J*D (lmbc_core.c:562-569) folded into the reduced products
           for (int i = 0; i < M; ++i) {
             h.jte[i] *= c.dscl[i];
@@ -977,14 +1121,23 @@ struct BcMachine {
           ph = B_END_ITER;
           break;
         }
-        request_eval(c, h, req, v);
+        if (SPECJ && c.spec_jac)
+          request_eval_jac(c, h, req, v);
+        else
+          request_eval(c, h, req, v);
         ph = B_AFTER_LM_EVAL;
         { h.phase = ph; return; }
       } LM_PHASE_END
 
       LM_PHASE(B_AFTER_LM_EVAL) {  // overflow guard, lmbc_core.c:748-751
-        h.pdp_e2 = s[0];
+        h.pdp_e2 = candidate_e2<SPECJ>(h, cool, s);
         if (!lm_finite(h.pdp_e2)) {
+          if (SPECJ && h.spec_state == 1) {  // the guard wants max |e|, which a Jacobian pass does not form: evaluate plainly
+            h.spec_state = 0;
+            request_eval(c, h, req, h.pdp);
+            --h.nfev;  // (the same evaluation, asked for again)
+            { h.phase = ph; return; }
+          }
           if (!lm_finite(maxabs)) {
             h.stop = 7;
             ph = B_END_ITER;
@@ -1025,7 +1178,7 @@ struct BcMachine {
             h.mu = (h.mu >= q) ? q : h.mu;
           }
           h.nu = 2;
-          accept_trial(h);
+          accept_trial<SPECJ>(h);
           h.gprev = 0;
           ph = B_END_ITER;
           break;
@@ -1077,8 +1230,9 @@ struct BcMachine {
       } LM_PHASE_END
 
       LM_PHASE(B_LS_EVAL) {  // lmbc_core.c:269-332
-        const Real fpls = Real(0.5) * s[0];
-        h.pdp_e2 = s[0];
+        const Real e2 = candidate_e2<SPECJ>(h, cool, s);
+        const Real fpls = Real(0.5) * e2;
+        h.pdp_e2 = e2;
         if (fpls <= cool.ls_f0 + cool.ls_slp * alpha * cool.ls_lambda) {  // satisfactory point
           if (!lm_finite(h.pdp_e2)) {  // lmbc_core.c:828
             ph = B_PG_BEGIN;
@@ -1132,6 +1286,12 @@ struct BcMachine {
         const Real lam = cool.ls_lambda;
         for (int i = M; i-- > 0;) v[i] = h.p[i] + lam * h.dp[i];
         project(c, v);
+        if (SPECJ && c.spec_jac) {  // (no dscl with spec_jac)
+          for (int i = 0; i < M; ++i) h.pdp[i] = v[i];
+          request_eval_jac(c, h, req, v);
+          ph = B_LS_EVAL;
+          { h.phase = ph; return; }
+        }
         req.kind = RQ_EVAL;
         req.scal = Real(1.0);
         if (!c.has_dscl) {
@@ -1270,6 +1430,7 @@ struct BcMachine {
       } LM_PHASE_END
 
       LM_PHASE(B_PG_ISSUE) {  // loop head of lmbc_core.c:885
+        if (SPECJ) h.spec_state = 0;  // projected-gradient candidates are plain evaluations: nothing kept for them
         if (!(h.t > tming)) {  // search failed, :937-939
           h.gprev = 0;
           ph = B_END_ITER;
@@ -1329,7 +1490,7 @@ struct BcMachine {
           ph = B_END_ITER;
           break;
         }
-        accept_trial(h);
+        accept_trial<SPECJ>(h);
         ph = B_END_ITER;
         break;
       } LM_PHASE_END
@@ -1348,6 +1509,12 @@ struct BcMachine {
         if (h.p_e2 <= c.o.eps3) {
           h.stop = 6;
           ph = B_FINISH;
+          break;
+        }
+        if (SPECJ && h.spec_state == 2) {  // this point was evaluated by a Jacobian pass when it was a candidate
+          h.spec_state = 3;
+          ++h.njev;
+          ph = B_AFTER_JAC;
           break;
         }
         clear_req(h, req);  // FD Jacobian at the unscaled point, lmbc_core.c:555-561 + :1043-1054

@@ -91,6 +91,8 @@ struct ResidentCtx {
   // host starts one too, for the argument checks and warnings of the entry point, but nothing is uploaded)
   double p0[kM], opts[5], lb[kM], ub[kM], dscl[kM];
   int itmax, has_opts, has_lb, has_ub, has_dscl, want_covar, multi, analytic;
+  int chain;     // dlevmar_dif: trial points per sweep in a chain of rejections (DifMachine::Cold::multi)
+  int spec_jac;  // dlevmar_bc_dif / bc_der: candidates evaluated by Jacobian passes (BcMachine::Cold::spec_jac)
   Mailbox *mbox;
   int n;
   unsigned tag_base;  // tags of this launch are tag_base + epoch + 1: the rows need no zeroing between launches
@@ -428,8 +430,8 @@ __device__ __forceinline__ void sweep_pass(int kind, const PassUniforms<MODEL> &
       });
     }
     break;
-  case RQ_EVAL_MULTI:
-    if constexpr (METHOD != 0) {
+  case RQ_EVAL_MULTI:  // bc: candidates of a projected-gradient search; dif: the trial points of a chain of rejections
+    if constexpr (METHOD != 2) {
       for_samples<U>(nk, [&](int k) {
         const double c0 = st.get(kFc0, k), x = st.get(kFx, k);
         const Prep q = prep(k);
@@ -542,13 +544,16 @@ __device__ __forceinline__ void reduce_pass(int kind, const double *acc, double 
     switch (kind) {
     case RQ_DIF_JAC: worker_reduce<SumLayout<kM>::DIF_JAC, false>(acc, mx, red, sums, st_, last_); break;
     case RQ_DIF_TRIAL: worker_reduce<kTrialSums, false>(acc, mx, red, sums, st_, last_); break;
+    case RQ_EVAL_MULTI: worker_reduce<kMaxCand, false>(acc, mx, red, sums, st_, last_); break;
     default: worker_reduce<1, false>(acc, mx, red, sums, st_, last_); break;
     }
   } else {
     switch (kind) {
-    case RQ_JAC: worker_reduce<SumLayout<kM>::JAC>(acc, mx, red, sums, st_, last_); break;
-    case RQ_EVAL_MULTI: worker_reduce<kMaxCand>(acc, mx, red, sums, st_, last_); break;
-    default: worker_reduce<1>(acc, mx, red, sums, st_, last_); break;
+    // (max |e| is read after plain evaluations only -- the overflow guards of lmbc_core.c:748, :915 -- so the Jacobian and
+    // multi-candidate passes carry no max slot: one reduction value, one exchange cell and one gather instruction less)
+    case RQ_JAC: worker_reduce<SumLayout<kM>::JAC, false>(acc, mx, red, sums, st_, last_); break;
+    case RQ_EVAL_MULTI: worker_reduce<kMaxCand, false>(acc, mx, red, sums, st_, last_); break;
+    default: worker_reduce<1, METHOD == 1>(acc, mx, red, sums, st_, last_); break;  // (dlevmar_der never reads max |e|)
     }
   }
 }
@@ -593,7 +598,7 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
     // (the arguments are copied into locals first: handing start() pointers INTO the by-value argument structs makes hipcc
     // spill the whole struct to scratch and serve every later ctx.field access from there -- measured +1.3 us per pass)
     double p0[kM], opts[5], lb[kM], ub[kM], dscl[kM];
-    int itmax, has_opts, has_lb, has_ub, has_dscl = 0, want_covar = 0, multi, analytic;
+    int itmax, has_opts, has_lb, has_ub, has_dscl = 0, want_covar = 0, multi, analytic, chain, spec_jac;
     if constexpr (BATCHED) {
 #pragma unroll
       for (int i = 0; i < kM; ++i) {
@@ -605,6 +610,7 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
 #pragma unroll
       for (int i = 0; i < 5; ++i) opts[i] = bctx.opts[i];
       itmax = bctx.itmax, has_opts = bctx.has_opts, has_lb = bctx.has_lb, has_ub = bctx.has_ub, multi = bctx.multi, analytic = bctx.analytic;
+      chain = bctx.chain, spec_jac = bctx.spec_jac;
     } else {
 #pragma unroll
       for (int i = 0; i < kM; ++i) {
@@ -616,18 +622,18 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
 #pragma unroll
       for (int i = 0; i < 5; ++i) opts[i] = ctx.opts[i];
       itmax = ctx.itmax, has_opts = ctx.has_opts, has_lb = ctx.has_lb, has_ub = ctx.has_ub, has_dscl = ctx.has_dscl;
-      want_covar = ctx.want_covar, multi = ctx.multi, analytic = ctx.analytic;
+      want_covar = ctx.want_covar, multi = ctx.multi, analytic = ctx.analytic, chain = ctx.chain, spec_jac = ctx.spec_jac;
     }
     const double *po = has_opts ? opts : nullptr;
     if constexpr (METHOD == 0) {
-      sm.start(p0, n, itmax, po, want_covar, /*speculative=*/1);
+      sm.start(p0, n, itmax, po, want_covar, /*speculative=*/1, chain);
     } else if constexpr (METHOD == 1) {
-      sm.start(p0, n, has_lb ? lb : nullptr, has_ub ? ub : nullptr, has_dscl ? dscl : nullptr, itmax, po, want_covar, multi);
+      sm.start(p0, n, has_lb ? lb : nullptr, has_ub ? ub : nullptr, has_dscl ? dscl : nullptr, itmax, po, want_covar, multi, spec_jac);
       sm.c.analytic_jac = analytic;
     } else {
       sm.start(p0, n, itmax, po, want_covar);
     }
-    (void)analytic;
+    (void)analytic, (void)chain, (void)spec_jac;
   }
   if (tid == 0) s_abort = s_bad = 0;
   if (tid <= kM) dp_prev[tid] = 0.0;
@@ -767,13 +773,14 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
           switch (kind) {
           case RQ_DIF_JAC: alive = control_exchange<SumLayout<kM>::DIF_JAC, false>(ctx, epoch, sums, &s_abort, st_, last_); break;
           case RQ_DIF_TRIAL: alive = control_exchange<kTrialSums, false>(ctx, epoch, sums, &s_abort, st_, last_); break;
+          case RQ_EVAL_MULTI: alive = control_exchange<kMaxCand, false>(ctx, epoch, sums, &s_abort, st_, last_); break;
           default: alive = control_exchange<1, false>(ctx, epoch, sums, &s_abort, st_, last_); break;
           }
         } else {
           switch (kind) {
-          case RQ_JAC: alive = control_exchange<SumLayout<kM>::JAC>(ctx, epoch, sums, &s_abort, st_, last_); break;
-          case RQ_EVAL_MULTI: alive = control_exchange<kMaxCand>(ctx, epoch, sums, &s_abort, st_, last_); break;
-          default: alive = control_exchange<1>(ctx, epoch, sums, &s_abort, st_, last_); break;
+          case RQ_JAC: alive = control_exchange<SumLayout<kM>::JAC, false>(ctx, epoch, sums, &s_abort, st_, last_); break;
+          case RQ_EVAL_MULTI: alive = control_exchange<kMaxCand, false>(ctx, epoch, sums, &s_abort, st_, last_); break;
+          default: alive = control_exchange<1, METHOD == 1>(ctx, epoch, sums, &s_abort, st_, last_); break;
           }
         }
        }
@@ -797,11 +804,16 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
       // (hcore, loaded before the loop); Cool and the request stay in LDS, where the other waves read the request.
       if constexpr (kCoreInRegs) {
         if constexpr (METHOD == 0)
-          Machine::template run<true>(sm.c, hcore, sm.h.cool, sm.h.req, sums, sums[kSums]);
+          Machine::template run<true, true>(sm.c, hcore, sm.h.cool, sm.h.req, sums, sums[kSums]);
         else
           Machine::template run<true>(sm.c, hcore, sm.h.req, sums, sums[kSums]);
       } else {
-        sm.template step<true>(sums, sums[kSums]);
+        if constexpr (METHOD == 0)
+          sm.template step<true, true>(sums, sums[kSums]);  // (+ chains of rejections, several trial points to a sweep)
+        else if constexpr (METHOD == 1)
+          sm.template step<true, true, false, true>(sums, sums[kSums]);  // (+ candidates evaluated by Jacobian passes)
+        else
+          sm.template step<true>(sums, sums[kSums]);
       }
       RSTAMP(7);  // the step alone
       if (sm.h.req.kind != RQ_DONE) {
@@ -1002,6 +1014,8 @@ int resident_attempt(const StreamFitArgs &a, RWorkspace &ws, bool *retry_exact, 
   c.has_dscl = METHOD == 1 && a.dscl != nullptr;
   c.want_covar = a.covar != nullptr;
   c.multi = pg_candidates();
+  c.chain = dif_chain_candidates();
+  c.spec_jac = bc_spec_jac_enabled() ? 1 : 0;
   c.analytic = a.analytic ? 1 : 0;
   c.mbox = ws.d_mbox;
   c.n = a.n;

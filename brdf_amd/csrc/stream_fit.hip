@@ -131,7 +131,14 @@ __global__ __launch_bounds__(kStreamThreads, kStreamWavesPerSimd) void stream_pa
     const int kind_before_ = sm.h.req.kind, phase_before_ = sm.h.phase;
     const long long ts0_ = clock64();
 #endif
-    if (first_wave) sm.template step<true>(sums, sums[kSums]);
+    if (first_wave) {  // (dif: + chains of rejections sharing a sweep; bc: + candidates evaluated by Jacobian passes -- lm_machine.h)
+      if constexpr (METHOD == 0)
+        sm.template step<true, true>(sums, sums[kSums]);
+      else if constexpr (METHOD == 1)
+        sm.template step<true, true, false, true>(sums, sums[kSums]);
+      else
+        sm.template step<true>(sums, sums[kSums]);
+    }
 #ifdef BRDF_STAMPS
     if (blockIdx.x == 0 && tid == 0 && pass < 4096) {
       ctx->dbg[pass * 4 + 0] = (int)(clock64() - ts0_);
@@ -539,7 +546,7 @@ static int stream_fit_attempt(const StreamFitArgs &a, bool fast, bool *retry_exa
 
   if (a.method == 0) {
     DifMachine<kM> &m = h.m[0].dif;
-    m.start(a.p, a.n, a.itmax, a.opts, a.covar != nullptr);
+    m.start(a.p, a.n, a.itmax, a.opts, a.covar != nullptr, /*speculative=*/1, dif_chain_candidates());
     if (m.h.req.kind == RQ_DONE) {
       set_error("dlevmar_dif(): cannot solve a problem with fewer measurements [%d] than unknowns [%d]", a.n, kM);
       return kLmError;
@@ -553,7 +560,7 @@ static int stream_fit_attempt(const StreamFitArgs &a, bool fast, bool *retry_exa
     }
   } else {
     BcMachine<kM> &m = h.m[0].bc;
-    m.start(a.p, a.n, a.lb, a.ub, a.dscl, a.itmax, a.opts, a.covar != nullptr, pg_candidates());
+    m.start(a.p, a.n, a.lb, a.ub, a.dscl, a.itmax, a.opts, a.covar != nullptr, pg_candidates(), bc_spec_jac_enabled() ? 1 : 0);
     m.c.analytic_jac = a.analytic ? 1 : 0;
     if (m.h.req.kind == RQ_DONE) {
       switch (m.c.bad_input) {
@@ -644,6 +651,21 @@ int pg_candidates() {
   const char *e = getenv("BRDF_HIP_PG_MULTI");
   const int k = e ? atoi(e) : kMaxCand;
   return k < 1 ? 1 : (k > kMaxCand ? kMaxCand : k);
+}
+
+// BRDF_HIP_DIF_CHAIN=k: dlevmar_dif trial points per sweep in a chain of rejections (lm_machine.h: DifMachine::Cold::multi;
+// default 8, 1 = one at a time)
+int dif_chain_candidates() {
+  const char *e = getenv("BRDF_HIP_DIF_CHAIN");
+  const int k = e ? atoi(e) : kMaxCand;
+  return k < 1 ? 1 : (k > kMaxCand ? kMaxCand : k);
+}
+
+// BRDF_HIP_SPEC_JAC=0: single dlevmar_bc_dif / bc_der fits evaluate their candidates by plain evaluation passes (default: by
+// Jacobian passes, lm_machine.h: BcMachine::Cold::spec_jac)
+bool bc_spec_jac_enabled() {
+  const char *e = getenv("BRDF_HIP_SPEC_JAC");
+  return !(e && e[0] == '0');
 }
 
 // BRDF_HIP_EXACT_POW=1 forces the exact model path (reference expression, pow per evaluation)

@@ -19,6 +19,8 @@ namespace {
 
 int g_speculative = 1;  // dif protocol under test (see lm_machine.h)
 int g_multi = 1;        // bc: candidates per projected-gradient sweep
+int g_dif_multi = 1;    // dif: trial points per sweep in a chain of rejections (DifMachine::Cold::multi)
+int g_spec_jac = 0;     // bc: candidates evaluated by Jacobian passes (BcMachine::Cold::spec_jac)
 
 template <int MODEL, bool FAST>
 struct HostPasses {
@@ -164,11 +166,11 @@ int fit(int method, double *angles, double *x, int n, double *p, int itmax, doub
     HostPasses<MODEL, FAST> hp(angles, x, n, 0);
     hp.speculative = g_speculative;
     DifMachine<3> m;
-    m.start(p, n, itmax, opts, covar != nullptr, g_speculative);
+    m.start(p, n, itmax, opts, covar != nullptr, g_speculative, g_dif_multi);
     while (m.h.req.kind != RQ_DONE) {
       hp.run(m.h.req, s, mx);
       ++np;
-      m.step(s, mx);
+      m.template step<false, true>(s, mx);
     }
     for (int i = 0; i < 3; ++i) p[i] = m.h.p[i];
     if (info) for (int i = 0; i < 10; ++i) info[i] = m.c.info[i];
@@ -195,12 +197,12 @@ int fit(int method, double *angles, double *x, int n, double *p, int itmax, doub
   HostPasses<MODEL, FAST> hp(angles, x, n, 1);
   hp.analytic = (method == 2);
   BcMachine<3> m;
-  m.start(p, n, lb, ub, dscl, itmax, opts, covar != nullptr, g_multi);
+  m.start(p, n, lb, ub, dscl, itmax, opts, covar != nullptr, g_multi, g_spec_jac);
   m.c.analytic_jac = (method == 2) ? 1 : 0;
   while (m.h.req.kind != RQ_DONE) {
     hp.run(m.h.req, s, mx);
     ++np;
-    m.step(s, mx);
+    m.template step<false, true, false, true>(s, mx);
   }
   for (int i = 0; i < 3; ++i) p[i] = m.h.p[i];
   if (info) for (int i = 0; i < 10; ++i) info[i] = m.c.info[i];
@@ -236,3 +238,5 @@ extern "C" int hm_brdf_fit_fast(int method, int model, double *angles, double *x
 
 extern "C" void hm_set_dif_protocol(int speculative) { g_speculative = speculative; }
 extern "C" void hm_set_bc_multi(int k) { g_multi = k; }
+extern "C" void hm_set_dif_multi(int k) { g_dif_multi = k; }
+extern "C" void hm_set_bc_spec_jac(int on) { g_spec_jac = on; }

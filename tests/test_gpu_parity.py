@@ -248,13 +248,45 @@ def test_full_size_properties(gpu, method, model):
     hx = brdf_amd.model_eval(model, a, res.p).cpu().numpy()
     assert abs(float(np.sum((x - hx) ** 2)) - res.info[1]) <= 1e-10 * res.info[1]
     st = brdf_amd.last_fit_stats()
+    # levmar's evaluation count against the sweeps the launch made: one sweep per Jacobian, at most one per evaluation
+    # (a chain of rejections shares a sweep, a candidate that is taken brings the next iteration's Jacobian with it)
     if method == 0:
-        assert res.info[7] == 1 + 3 * res.info[8] + (st["passes"] - 1 - st["jac_passes"])
+        assert st["passes"] <= 1 + res.info[8] + (res.info[7] - 1 - 3 * res.info[8])
     else:
-        assert res.info[7] == st["eval_passes"] + 4 * st["jac_passes"]
+        assert st["passes"] <= res.info[8] + (res.info[7] - 4 * res.info[8])
     again = brdf_amd.fit_single(method, model, a, xd, res.p, lb=synth.LB, ub=synth.UB, itmax=synth.ITMAX,
                                 opts=synth.OPTS)
     assert again.ret >= 0 and L.rel_err(again.p, res.p) <= 1e-6 and again.info[1] <= res.info[1] * (1 + 1e-9)
+
+
+@pytest.mark.parametrize("model,n", [(2, 1_000_000), (1, 1_000_000), (2, 100003), (0, 5000), (1, 300)])
+def test_shared_sweeps_do_not_change_a_bit(gpu, monkeypatch, model, n):
+    """Fewer sweeps, same arithmetic.  dlevmar_dif evaluates the trial points of a chain of rejections up to eight to a sweep
+    (BRDF_HIP_DIF_CHAIN); dlevmar_bc_dif / bc_der evaluate a candidate by the Jacobian pass the next iteration would open with
+    (BRDF_HIP_SPEC_JAC).  Every sum that is judged is formed by the same per-lane order and the same trees as in the plain
+    passes, so p, info[] (iterations, nfev, njev, nlss) and the covariance must be bit-identical with and without them --
+    in the resident regime and in the launch chain."""
+    torch, brdf_amd, dev = gpu
+    angles, x, _ = synth.make_single(model, n)
+    fewer = 0
+    for regime in ("1", "0"):
+        monkeypatch.setenv("BRDF_HIP_RESIDENT", regime)
+        for method in (0, 1, 2):
+            lb, ub = synth.bounds(model) if method == 2 else (synth.LB, synth.UB)
+            got = []
+            for on in ("8", "1"):
+                monkeypatch.setenv("BRDF_HIP_DIF_CHAIN", on)
+                monkeypatch.setenv("BRDF_HIP_SPEC_JAC", "1" if on == "8" else "0")
+                r = _dev_fit(gpu, method, model, angles, x, lb=lb, ub=ub, want_covar=True)
+                got.append((r, brdf_amd.last_fit_stats()["passes"]))
+            (a, pa), (b, pb) = got
+            what = (regime, method, [float(v).hex() for v in a.info], [float(v).hex() for v in b.info])
+            assert a.ret == b.ret and np.array_equal(a.p, b.p), what
+            assert np.array_equal(a.info, b.info), what
+            assert np.array_equal(a.covar, b.covar), (regime, method, a.covar, b.covar)
+            assert pa <= pb
+            fewer += pb - pa
+    assert fewer > 0
 
 
 # ---- batched regime ------------------------------------------------------------------------------------
@@ -555,7 +587,8 @@ def test_bc_der_with_the_analytic_device_jacobian(gpu, model, monkeypatch):
             monkeypatch.setenv("BRDF_HIP_RESIDENT", env)
             res = _dev_fit(gpu, 2, model, angles, x, lb=lb, ub=ub)
             _check(res, p_ref, info_ref)
-            assert res.info[8] == brdf_amd.last_fit_stats()["jac_passes"]  # one pass per Jacobian
+            st = brdf_amd.last_fit_stats()  # at most one pass per Jacobian and one per evaluation (candidates evaluated by the
+            assert res.info[8] <= st["jac_passes"] and st["passes"] <= res.info[8] + res.info[7]  # next Jacobian's pass share it)
         res = brdf_amd.host_dlevmar(2, model, angles, x, synth.P0[model], lb=lb, ub=ub, itmax=synth.ITMAX, opts=synth.OPTS)
         _check(res, p_ref, info_ref)
     # BRDFJac_hip and dlevmar_chkjac through host pointers

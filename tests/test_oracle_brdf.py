@@ -160,6 +160,99 @@ def test_multi_candidate_projected_gradient_is_bit_exact(k):
         L.hm.hm_set_bc_multi(1)
 
 
+def _hm_passes(method, model, angles, x, p0, itmax, opts, lb, ub):
+    """hm_brdf_fit with the number of passes (sweeps over the samples) the machine asked for"""
+    a, xx = L.f64(angles), L.f64(x)
+    p = L.f64(p0).copy()
+    info = np.zeros(10)
+    o, l, u = L.f64(opts), L.f64(lb), L.f64(ub)
+    passes = C.c_int(0)
+    bc = method in (1, 2)
+    r = L.hm.hm_brdf_fit(method, model, L.ptr(a), L.ptr(xx), xx.size, L.ptr(p), itmax, L.ptr(o), L.ptr(l) if bc else None,
+                         L.ptr(u) if bc else None, None, L.ptr(info), None, C.byref(passes))
+    return r, p, info, passes.value
+
+
+@pytest.mark.parametrize("k", [2, 3, 8])
+def test_rejection_chains_evaluated_together_are_bit_exact(k):
+    """dlevmar_dif, DifMachine::Cold::multi = k: once a trial has been rejected without a Broyden update (no step taken
+    since the fresh Jacobian, lm_core.c:757), the trial points of the next rejections differ by their damping only and are
+    evaluated k to a sweep.  Judged in the reference's order, only the judged ones counted: p and info[] -- iterations,
+    nfev, nlss included -- are the reference's for every fixture and for ragged random fits, in fewer passes."""
+    saved = 0
+    try:
+        for f in FITS:
+            if f["method"] != 0:
+                continue
+            angles, x, _ = synth.make_single(f["model"], f["n"])
+            args = (0, f["model"], angles, x, synth.P0[f["model"]], synth.ITMAX, synth.OPTS, synth.LB, synth.UB)
+            L.hm.hm_set_dif_multi(1)
+            _, _, _, base = _hm_passes(*args)
+            L.hm.hm_set_dif_multi(k)
+            r, p, info, passes = _hm_passes(*args)
+            assert r == f["ret"] and np.array_equal(p, _hex(f["p"])) and np.array_equal(info, _hex(f["info"]))
+            assert passes <= base + 2  # (a candidate that reduces the error is evaluated again by the plain trial pass)
+            saved += base - passes
+        assert saved > 0
+        for seed in (1, 2, 3, 4, 5, 6):
+            for n in (3, 5, 17, 100, 257):
+                model = seed % 3
+                angles, x, _ = synth.make_surfels(model, n, first=seed * 1000, count=1, seed=synth.SEED + seed)
+                a = L.brdf_fit("orc", 0, model, angles[0], x[0], synth.P0[model], 60, synth.OPTS, synth.LB, synth.UB)
+                b = L.brdf_fit("hm", 0, model, angles[0], x[0], synth.P0[model], 60, synth.OPTS, synth.LB, synth.UB)
+                assert a[0] == b[0] and np.array_equal(a[1], b[1], equal_nan=True) and np.array_equal(a[2], b[2], equal_nan=True)
+        o = list(synth.OPTS)
+        o[4] = -1e-6  # central differences; then the default options
+        angles, x, _ = synth.make_single(1, 200)
+        for opts in (o, None):
+            a = L.brdf_fit("orc", 0, 1, angles, x, synth.P0[1], 100, opts, synth.LB, synth.UB)
+            b = L.brdf_fit("hm", 0, 1, angles, x, synth.P0[1], 100, opts, synth.LB, synth.UB)
+            assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    finally:
+        L.hm.hm_set_dif_multi(1)
+
+
+@pytest.mark.parametrize("pg", [1, 8])
+def test_candidates_evaluated_by_jacobian_passes_are_bit_exact(pg):
+    """dlevmar_bc_dif / dlevmar_bc_der, BcMachine::Cold::spec_jac: the LM trial point, every line-search point and the
+    start are evaluated by a Jacobian pass at that point; when the candidate is taken the next iteration's Jacobian
+    (lmbc_core.c:555-561) is already there.  Same p, same info[] (nfev, njev), one pass per accepted iteration less."""
+    saved = 0
+    L.hm.hm_set_bc_multi(pg)
+    try:
+        for f in FITS:
+            if f["method"] not in (1, 2):
+                continue
+            angles, x, _ = synth.make_single(f["model"], f["n"])
+            args = (f["method"], f["model"], angles, x, synth.P0[f["model"]], synth.ITMAX, synth.OPTS, synth.LB, synth.UB)
+            L.hm.hm_set_bc_spec_jac(0)
+            _, _, _, base = _hm_passes(*args)
+            L.hm.hm_set_bc_spec_jac(1)
+            r, p, info, passes = _hm_passes(*args)
+            assert r == f["ret"] and np.array_equal(p, _hex(f["p"])) and np.array_equal(info, _hex(f["info"]))
+            assert passes < base
+            saved += base - passes
+        assert saved > 0
+        L.hm.hm_set_bc_spec_jac(1)
+        for seed in (1, 2, 3, 4, 5, 6):
+            for n in (3, 5, 17, 100, 257):
+                model = seed % 3
+                angles, x, _ = synth.make_surfels(model, n, first=seed * 1000, count=1, seed=synth.SEED + seed)
+                a = L.brdf_fit("orc", 1, model, angles[0], x[0], synth.P0[model], 60, synth.OPTS, synth.LB, synth.UB)
+                b = L.brdf_fit("hm", 1, model, angles[0], x[0], synth.P0[model], 60, synth.OPTS, synth.LB, synth.UB)
+                assert a[0] == b[0] and np.array_equal(a[1], b[1], equal_nan=True) and np.array_equal(a[2], b[2], equal_nan=True)
+        o = list(synth.OPTS)
+        o[4] = -1e-6
+        angles, x, _ = synth.make_single(1, 200)
+        for opts, p0 in ((o, synth.P0[1]), (None, synth.P0[1]), (synth.OPTS, [-1.0, 150.0, 1.0])):  # central, defaults, infeasible start
+            a = L.brdf_fit("orc", 1, 1, angles, x, p0, 100, opts, synth.LB, synth.UB)
+            b = L.brdf_fit("hm", 1, 1, angles, x, p0, 100, opts, synth.LB, synth.UB)
+            assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    finally:
+        L.hm.hm_set_bc_spec_jac(0)
+        L.hm.hm_set_bc_multi(1)
+
+
 @pytest.mark.parametrize("model", [0, 1, 2])
 def test_analytic_jacobian_passes_the_references_own_chkjac(model):
     """the analytic Jacobian is ours (the reference only differentiates numerically), so
