@@ -136,6 +136,18 @@ LM_HD int lm_uniform(int v) {
 #endif
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// lane `lane`'s value of v (lane: a compile-time constant after unrolling)
+__device__ __forceinline__ double lm_read_lane(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float lm_read_lane(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+#endif
+
 template <class Real>
 LM_HD Real lm_abs(Real v) { return (v >= Real(0.0)) ? v : -v; }
 template <class Real>
@@ -670,6 +682,42 @@ struct DifMachine {
           Real mu = h.mu;
           int nu = h.nu, kk = h.k, cnt = 0;
           const Real pl2 = h.p_l2;
+#if defined(__HIP_DEVICE_COMPILE__)
+          if (ONE_LANE) {
+            // On the device the step runs on all 64 lanes of a wave with identical values (MULTI is only compiled into kernels
+            // that step that way): the solves are independent given their damping, so lane j % 8 solves candidate j -- one LU's
+            // latency (~2,200 cycles) instead of eight -- and readlane collects the trial points.  Same arithmetic per
+            // candidate as the loop below, hence the same bits.
+            const int myj = (int)(__lane_id() & (kMaxCand - 1));
+            Real my_mu = mu;
+            int limit = 0;
+            for (int j = 0; j < kMaxCand; ++j) {  // the dampings of the chain (wave-uniform)
+              if (j >= c.multi || !(kk < c.itmax)) break;
+              if (j == myj) my_mu = mu;
+              limit = j + 1;
+              mu *= nu;
+              const int nu2 = (int)((unsigned)nu << 1);
+              if (nu2 <= nu) break;
+              nu = nu2;
+              ++kk;
+            }
+            Real dpj[M], q[M], l2 = Real(0.0);
+            for (int i = 0; i < M; ++i) A[i * M + i] = cool.diag[i] + my_mu;
+            bool ok = lu_solve<M>(A, b, dpj) != 0;
+            for (int i = 0; i < M; ++i) {
+              q[i] = pc[i] + dpj[i];
+              l2 += dpj[i] * dpj[i];
+            }
+            ok = ok && !(l2 <= c.o.eps2sq * pl2 || l2 >= (pl2 + c.o.eps2) / (Real(kEpsilon) * Real(kEpsilon)));
+            const unsigned good = (unsigned)__builtin_amdgcn_ballot_w64(ok) & 0xFFu;  // bit j: candidate j would be evaluated
+            for (int j = 0; j < kMaxCand; ++j) {
+              if (j >= limit || !(good >> j & 1u)) break;
+              for (int i = 0; i < M; ++i) req.pk[j][i] = lm_read_lane(q[i], j);
+              cool.ml2[j] = lm_read_lane(l2, j);
+              ++cnt;
+            }
+          } else
+#endif
           for (int j = 0; j < kMaxCand; ++j) {
             if (j >= c.multi || !(kk < c.itmax)) break;
             Real dpj[M];

@@ -181,6 +181,27 @@ __device__ __forceinline__ void for_samples(int nk, F &&f) {
   }
 }
 
+// two samples per guarded block where both exist: one sample's dependent chains (exp, the row differences, ten accumulations)
+// leave the fp64 pipe idle a third of the time with two waves per SIMD, two samples in one basic block let the scheduler
+// interleave them.  For the kernels whose register budget has the room (everything but the dlevmar_dif trial sweep).
+template <bool UNROLLED, class F>
+__device__ __forceinline__ void for_sample_pairs(int nk, F &&f) {
+  if constexpr (UNROLLED) {
+#pragma unroll
+    for (int k = 0; k < kRSpt; k += 2) {
+      if (k + 1 < nk) {
+        f(k);
+        f(k + 1);
+      } else if (k < nk) {
+        f(k);
+      }
+    }
+  } else {
+#pragma unroll 2
+    for (int k = 0; k < nk; ++k) f(k);
+  }
+}
+
 // Reduction of NS sums and one max over the eight waves: two DPP steps inside each row of 16 lanes leave the sum of
 // every 4 consecutive lanes in lanes 3,7,11,..; those park their values as buf[slot][thread/4]; wave w then owns slots
 // {w, w+8}: each lane adds its two entries and one DPP tree per slot finishes it.  A pure function of NS: reproducible.
@@ -397,7 +418,8 @@ __device__ __forceinline__ bool control_exchange(const ResidentCtx &ctx, unsigne
 // lane's partial sums in acc[] / mx and returns the number of sum slots of the request kind (a wave-uniform value).
 // `pend` (dlevmar_dif): the machine adopted the Broyden update of the previous trial; tb[] holds its scalar and
 // dpp[] its Dp: J += tb Dp^T is applied to the row while it is being read (lm_core.c:760-766).
-template <int MODEL, int METHOD, bool FAST, class Store>
+// PAIRS: two samples per guarded block in the evaluation / Jacobian sweeps (for_sample_pairs)
+template <int MODEL, int METHOD, bool FAST, bool PAIRS, class Store>
 __device__ __forceinline__ void sweep_pass(int kind, const PassUniforms<MODEL> &u, Store &st, double *jl, int tid, int nk, int nfull, unsigned okm,
                                            bool pend, const double *dpp, double *acc, double &mx) {
   constexpr bool U = Store::kUnrolled;
@@ -408,10 +430,23 @@ __device__ __forceinline__ void sweep_pass(int kind, const PassUniforms<MODEL> &
   // workgroup of a single fit holds up to #workgroups - 1 samples fewer than a tile, so its slot nk - 2 can be partly
   // empty and its slot nk - 1 entirely -- e.g. n = 262,145 on 256 CUs: tile 1025, last workgroup 770 samples.)
   auto dead = [&](int k) { return k >= nfull && !(okm >> k & 1u); };
+  // (measured, production builds, 10^6-sample Ward dlevmar_bc_dif with every candidate a Jacobian pass: 178 us per fit with
+  // pairs against 172 without -- the register-resident Jacobian body already interleaves its two exp chains; off by default)
+#ifdef BRDF_BC_PAIRS
+  constexpr bool kPairs = PAIRS;
+#else
+  constexpr bool kPairs = false;
+#endif
+  auto for_bc = [&](auto &&f) {
+    if constexpr (kPairs)
+      for_sample_pairs<U>(nk, f);
+    else
+      for_samples<U>(nk, f);
+  };
   switch (kind) {
   case RQ_EVAL:  // (the four kinds only dlevmar_bc_dif / bc_der / der issue are compiled into those kernels only)
     if constexpr (METHOD != 0) {
-      for_samples<U>(nk, [&](int k) {
+      for_bc([&](int k) {
         const double f = model_value<MODEL, FAST>(u, st.get(kFc0, k), prep(k));
         double e = st.get(kFx, k) - f;
         if (dead(k)) e = 0.0;
@@ -422,7 +457,7 @@ __device__ __forceinline__ void sweep_pass(int kind, const PassUniforms<MODEL> &
     break;
   case RQ_SCALED:
     if constexpr (METHOD != 0) {
-      for_samples<U>(nk, [&](int k) {
+      for_bc([&](int k) {
         const double f = model_value<MODEL, FAST>(u, st.get(kFc0, k), prep(k));
         double t = (st.get(kFx, k) - f) / u.scal;
         if (dead(k)) t = 0.0;
@@ -447,7 +482,7 @@ __device__ __forceinline__ void sweep_pass(int kind, const PassUniforms<MODEL> &
     break;
   case RQ_JAC:
     if constexpr (METHOD != 0) {
-      for_samples<U>(nk, [&](int k) {
+      for_bc([&](int k) {
         double f0 = 0.0, j[kM];
         if (u.analytic)  // dlevmar_bc_der / dlevmar_der with the model's analytic Jacobian
           model_an_row<MODEL, FAST>(u, st.get(kFc0, k), prep(k), f0, j);
@@ -490,10 +525,10 @@ __device__ __forceinline__ void sweep_pass(int kind, const PassUniforms<MODEL> &
   case RQ_DIF_TRIAL:  // speculative protocol: the Broyden-updated row is formed for the sums only (see the file comment)
     if constexpr (METHOD == 0) {
       const double rinv = 1.0 / u.dp_l2;
-      for_samples<U>(nk, [&](int k) {
+      auto value_q = [&](int k) { return model_value_q<MODEL, FAST>(u, st.get(kFc0, k), prep(k)); };
+      auto body = [&](int k, const double w) {
         const int s = k * kRThreads + tid;
         const double h = st.get(kFhx, k), x = st.get(kFx, k);
-        const double w = model_value_q<MODEL, FAST>(u, st.get(kFc0, k), prep(k));
         double jo[kM] = {jl[s], jl[kRCap + s], jl[2 * kRCap + s]};
         if (pend) {  // adopt the previous trial's update: the same operation that formed its jn[] below
           const double tp = st.get(kFtb, k);
@@ -529,7 +564,10 @@ __device__ __forceinline__ void sweep_pass(int kind, const PassUniforms<MODEL> &
 #pragma unroll
         for (int j = 0; j < kM; ++j) acc[2 + kM + j] = fma(jn[j], en, acc[2 + kM + j]);
         acc[2 + 2 * kM] = fma(t, eo, acc[2 + 2 * kM]);
-      });
+      };
+      // (the exp chains of two samples side by side and the Broyden / accumulation halves one after the other was measured too:
+      // 455 against 446 us per 10^6-sample fit; whole bodies in pairs spill 28-36 VGPRs)
+      for_samples<U>(nk, [&](int k) { body(k, value_q(k)); });
     }
     break;
   default: break;  // unknown request: the control wave will not survive it either
@@ -744,10 +782,10 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
         const double dpp[kM] = {dp_prev[0], dp_prev[1], dp_prev[2]};
         if constexpr (kControlFromLds) {
           decisions(ls, pend);
-          sweep_pass<MODEL, METHOD, FAST>(kind, su, ls, jl, tid, nk, nfull, okm, pend, dpp, acc, mx);
+          sweep_pass<MODEL, METHOD, FAST, !BATCHED>(kind, su, ls, jl, tid, nk, nfull, okm, pend, dpp, acc, mx);
         } else {
           decisions(rs, pend);
-          sweep_pass<MODEL, METHOD, FAST>(kind, su, rs, jl, tid, nk, nfull, okm, pend, dpp, acc, mx);
+          sweep_pass<MODEL, METHOD, FAST, !BATCHED>(kind, su, rs, jl, tid, nk, nfull, okm, pend, dpp, acc, mx);
         }
         RSTAMP(5);  // the control wave's own sweep
         RTRACE(ctx, epoch, 1, wall_clock64());
@@ -875,7 +913,7 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
     for (int k = 0; k < kSums; ++k) acc[k] = 0.0;
     double mx = 0.0;
     const double dpp[kM] = {dp_prev[0], dp_prev[1], dp_prev[2]};
-    sweep_pass<MODEL, METHOD, FAST>(kind, su, rs, jl, tid, nk, nfull, okm, pend, dpp, acc, mx);
+    sweep_pass<MODEL, METHOD, FAST, !BATCHED>(kind, su, rs, jl, tid, nk, nfull, okm, pend, dpp, acc, mx);
 #ifdef BRDF_TRACE_WORKERS  // (diagnostic: when do the register-resident waves finish their sweeps? slots 6, 7 = waves 4, 7)
     if constexpr (!BATCHED) {
       if (wave == 4) RTRACE(ctx, wepoch, 6, wall_clock64());

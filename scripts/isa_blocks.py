@@ -30,11 +30,11 @@ if cur: blocks.append((name, cur))
 def cnt(b, pat): return sum(1 for x in b if re.match(pat, x))
 tot = sum(len(b) for _, b in blocks)
 print(f"kernel {lines[start]} blocks {len(blocks)} instructions {tot}")
-print("block instr f64 exp/rcp ds_rd ds_wr scratch rdlane wrlane waitcnt nop branch_to")
+print("block instr f64 ldexp exp/rcp ds_rd ds_wr scratch rdlane wrlane waitcnt nop branch_to")
 for nme, b in blocks:
     if len(b) < minins: continue
     f64 = cnt(b, r'v_(fma|mul|add|fmac|max|min|ldexp|rndne|trunc|cvt|div|rcp|rsq|sqrt|cmp\w*|cndmask)\w*_f64')
     ex = cnt(b, r'v_(exp|rcp|rsq|sqrt|log)\w*')
     br = [x.split()[-1] for x in b if x.startswith('s_cbranch') or x.startswith('s_branch')]
-    print(nme, len(b), f64, ex, cnt(b, r'ds_read|ds_load'), cnt(b, r'ds_write|ds_store'), cnt(b, r'scratch_'), cnt(b, r'v_readlane'),
+    print(nme, len(b), f64, cnt(b, r'v_ldexp_f64'), ex, cnt(b, r'ds_read|ds_load'), cnt(b, r'ds_write|ds_store'), cnt(b, r'scratch_'), cnt(b, r'v_readlane'),
           cnt(b, r'v_writelane'), cnt(b, r's_waitcnt'), cnt(b, r's_nop'), ','.join(br[-2:]))
