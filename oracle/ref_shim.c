@@ -10,19 +10,36 @@
 #include "levmar.h" /* the reference's header, via -I$(REF)/levmar */
 #include "oracle.h"
 
+/* The reference's OWN callback, compiled from its text (brdfdata.cpp:962-989 through ref_brdffunc.cpp; struct extraData has
+ * the layout of orc_extra_data): Phong and Blinn-Phong fits of the reference are driven by it.  Ward (modelInfo 2) is not in
+ * the reference: its callback is ours. */
+void ref_BRDFFunc(double *p, double *x, int m, int n, void *data);
+typedef void (*brdf_cb)(double *, double *, int, int, void *);
+static brdf_cb callback_of(int model) { return (model == 0 || model == 1) ? ref_BRDFFunc : orc_brdf_func; }
+
 int ref_brdf_fit(int method, int model, double *angles, double *x, int n, double *p, int itmax,
                  double *opts, double *lb, double *ub, double *info)
 {
   struct orc_extra_data d;
+  brdf_cb f = callback_of(model);
   d.angles = angles;
   d.modelInfo = model;
   if (method == 0)
-    return dlevmar_dif(orc_brdf_func, p, x, 3, n, itmax, opts, info, 0, 0, &d);
+    return dlevmar_dif(f, p, x, 3, n, itmax, opts, info, 0, 0, &d);
   if (method == 3) /* the reference's dlevmar_der driven by our analytic Jacobian */
-    return dlevmar_der(orc_brdf_func, orc_brdf_jac, p, x, 3, n, itmax, opts, info, 0, 0, &d);
+    return dlevmar_der(f, orc_brdf_jac, p, x, 3, n, itmax, opts, info, 0, 0, &d);
   if (method == 2) /* the reference's dlevmar_bc_der driven by our analytic Jacobian */
-    return dlevmar_bc_der(orc_brdf_func, orc_brdf_jac, p, x, 3, n, lb, ub, 0, itmax, opts, info, 0, 0, &d);
-  return dlevmar_bc_dif(orc_brdf_func, p, x, 3, n, lb, ub, 0, itmax, opts, info, 0, 0, &d);
+    return dlevmar_bc_der(f, orc_brdf_jac, p, x, 3, n, lb, ub, 0, itmax, opts, info, 0, 0, &d);
+  return dlevmar_bc_dif(f, p, x, 3, n, lb, ub, 0, itmax, opts, info, 0, 0, &d);
+}
+
+/* model values through the reference's own callback (models 0 / 1) */
+void ref_brdf_values(int model, double *angles, int n, double *p, double *hx)
+{
+  struct orc_extra_data d;
+  d.angles = angles;
+  d.modelInfo = model;
+  callback_of(model)(p, hx, 3, n, &d);
 }
 
 /* S independent fits, one after the other (the shape of CalcBRDFEquation's pixel loop,
@@ -44,7 +61,7 @@ void ref_brdf_chkjac(int model, double *angles, int n, double *p, double *err)
   struct orc_extra_data d;
   d.angles = angles;
   d.modelInfo = model;
-  dlevmar_chkjac(orc_brdf_func, orc_brdf_jac, p, 3, n, &d, err);
+  dlevmar_chkjac(callback_of(model), orc_brdf_jac, p, 3, n, &d, err);
 }
 
 /* ---- single-precision test problems (ours: textbook NLLS functions written for float callbacks; the reference's

@@ -1,7 +1,7 @@
 // tests/cpp/dropin_solve_equation.cpp -- the reference's call site, recompiled against libbrdf_hip.so.
 //
-// A C++ translation unit written the way CBRDFdata::SolveEquation is (brdfdata.cpp:1077-1136): its own
-// `struct extraData`, its own `BRDFFunc` with the reference's arithmetic (brdfdata.cpp:962-989), the same p0 /
+// A C++ translation unit written the way CBRDFdata::SolveEquation is (brdfdata.cpp:1077-1136): the reference's own
+// `struct extraData` and `BRDFFunc` (brdfdata.cpp:962-989, compiled from the reference's text, see below), the same p0 /
 // opts / bounds / itmax, `dlevmar_bc_dif(BRDFFunc, p, x, m, n, lower, upper, NULL, itmax, opts, info, NULL, NULL,
 // data)` -- and ONE added line, brdf_hip_register_model(BRDFFunc).  It includes the header under the name the
 // reference uses ("levmar.h" is provided by -include of include/brdf_levmar.h) and is linked with -lbrdf_hip
@@ -15,37 +15,16 @@
 
 #include "brdf_levmar.h"
 
-#define CV_PI 3.1415926535897932384626433832795
-
-// ---- EXCERPT of the reference, kept verbatim ON PURPOSE (brdfdata.cpp:962-989: struct extraData and BRDFFunc; only the
-// call counter is added): the point of this test is that the application's own callback and payload type compile
-// and link UNCHANGED against include/brdf_levmar.h + libbrdf_hip.so.  Everything below the excerpt is this test's own.
-struct extraData {
-  double *angles;
-  int modelInfo;
-};
-
-static long g_calls = 0;
-
-/* model to be fitted to measurements -- the application's callback */
-void BRDFFunc(double *p, double x[], int m, int n, void *data) {
-  extraData *incommingData = (extraData *)data;
-  double *angles = incommingData->angles;
-  int model = incommingData->modelInfo;
-  ++g_calls;
-  for (int i = 0; i < n; i++) {
-    double currCosPhi = angles[i];
-    if (model == 0) {
-      double currCosTheta = angles[i + n * 2];
-      x[i] = p[0] * currCosPhi + ((p[2] + 2.0) / 2.0 * CV_PI) * p[1] * (pow(currCosTheta, p[2]));
-    } else if (model == 1) {
-      double currCosThetaDash = angles[i + n];
-      x[i] = p[0] * currCosPhi + p[1] * (pow(currCosThetaDash, p[2]));
-    }
-  }
-  (void)m;
-}
-// ---- end of the excerpt ----------------------------------------------------------------------------------------------
+// The application's payload type and callback -- `struct extraData` and `BRDFFunc` -- are the REFERENCE's own text
+// (brdfdata.cpp:962-989), not a copy kept here: the Makefile cuts those lines out of /root/reference into a temporary file
+// and oracle/ref_brdffunc.cpp includes it (with OpenCV's CV_PI literal; REF_COUNT_POW routes the excerpt's pow() calls through
+// a counter so that this test can tell whether the callback's body ever ran).  The point of the test is that exactly that
+// text compiles and links UNCHANGED against include/brdf_levmar.h + libbrdf_hip.so.  Everything below is this test's own.
+long g_ref_brdffunc_pow_calls = 0;
+#define REF_COUNT_POW
+#define REF_BRDFFUNC_NO_EXPORT
+#include "../../oracle/ref_brdffunc.cpp"
+#undef pow
 
 int main(int argc, char **argv) {
   if (argc < 4) return 2;
@@ -67,7 +46,7 @@ int main(int argc, char **argv) {
   const int status = dlevmar_bc_dif(BRDFFunc, fit, samples.data() + 3 * (size_t)n, 3, n, box_lo, box_hi, NULL, 100, options, report,
                                     NULL, NULL, &payload);
   if (status == LM_ERROR) printf("Error in SolveEquation(..)\n");
-  printf("RESULT %d %ld", status, g_calls);
+  printf("RESULT %d %ld", status, g_ref_brdffunc_pow_calls);
   for (double v : fit) printf(" %a", v);
   for (double v : report) printf(" %a", v);
   printf("\n");

@@ -7,8 +7,11 @@
   lmdemo_kat.json  the reference's own known answers: lmdemo.c problems run through the compiled
                    reference (the same numbers as SURVEY.md section 4, here with full precision).
   slevmar_kat.json the single-precision twins: the compiled reference's slevmar_* on float test problems (ours, ref_shim.c)
-  model_values.json 64 model values per BRDF model from the restated callback (brdfdata.cpp:969-989
-                   arithmetic; Ward is build-defined).
+  model_values.json 64 model values per BRDF model.  Phong and Blinn-Phong: from `ref_BRDFFunc`, the REFERENCE's own
+                   BRDFFunc compiled from its text (brdfdata.cpp:962-989, cut out in place by oracle/Makefile's `ref`
+                   target; only OpenCV's CV_PI literal is supplied) -- this is what pins the model values.  Ward is
+                   build-defined: from the restated callback.
+  The BRDF fits of models 0 / 1 are driven by that same `ref_BRDFFunc` (oracle/ref_shim.c).
 """
 import ctypes as C
 import json
@@ -59,7 +62,9 @@ def main():
     for model in (0, 1, 2):
         angles, _, _ = synth.make_single(model, 64)
         for p in (synth.P0[model], synth.TRUTH[model]):
-            vals.append({"model": model, "p": list(p), "hx": [float.hex(v) for v in L.model_values(model, angles, p)]})
+            hx = L.ref_model_values(model, angles, p)  # models 0 / 1: ref_BRDFFunc; Ward: the restatement (not in the reference)
+            vals.append({"model": model, "p": list(p), "source": "ref_BRDFFunc (brdfdata.cpp:962-989 compiled in place)" if model < 2
+                         else "oracle/brdf_models_oracle.c (Ward is build-defined)", "hx": [float.hex(v) for v in hx]})
     json.dump({"n": 64, "values": vals}, open(os.path.join(HERE, "model_values.json"), "w"), indent=1)
     print("wrote", len(fits), "fits,", len(kats), "kats,", len(vals), "model value sets")
 

@@ -63,6 +63,17 @@ def model_values(model: int, angles, p):
     return hx
 
 
+def ref_model_values(model: int, angles, p):
+    """oracle/_ref: model values through the REFERENCE's own BRDFFunc (brdfdata.cpp:962-989 compiled in place) for models
+    0 / 1; Ward (not in the reference) through the restated callback"""
+    assert ref is not None, "oracle/_ref was not built"
+    a = f64(angles)
+    n = a.size // 3
+    hx = np.zeros(n)
+    ref.ref_brdf_values(model, ptr(a), n, ptr(f64(p).copy()), ptr(hx))
+    return hx
+
+
 def rel_err(p, p_ref):
     p, p_ref = np.asarray(p), np.asarray(p_ref)
     return float(np.max(np.abs(p - p_ref) / np.maximum(np.abs(p_ref), 1e-12)))

@@ -44,6 +44,19 @@ def test_model_values(entry):
     assert np.array_equal(L.model_values(entry["model"], angles, entry["p"]), _hex(entry["hx"]))
 
 
+@pytest.mark.skipif(L.ref is None, reason="the reference's BRDFFunc lives in oracle/_ref")
+@pytest.mark.parametrize("model", [0, 1])
+def test_restated_callback_equals_the_references_own_bit_for_bit(model):
+    """the model oracle is pinned by the reference's text: `ref_BRDFFunc` is BRDFFunc of brdfdata.cpp:962-989, cut out of
+    the reference where it lies and compiled by oracle/Makefile (only CV_PI supplied); the restatement every other
+    test uses (oracle/brdf_models_oracle.c) must give the same bits on seeded planes, odd sizes and edge exponents"""
+    rng = np.random.default_rng(7 + model)
+    for n in (1, 7, 64, 1000):
+        angles, _, _ = synth.make_single(model, n)
+        for p in (synth.P0[model], synth.TRUTH[model], [0.0, 0.0, 0.0], [1.5, 2.5, 0.5], list(rng.uniform(0.0, 60.0, 3))):
+            assert np.array_equal(L.model_values(model, angles, p), L.ref_model_values(model, angles, p), equal_nan=True)
+
+
 def test_phong_normalisation_is_times_pi():
     """brdfdata.cpp:981 multiplies by PI ((n+2)/2*PI); the viewer's (n+2)/(2 PI) is NOT what is fitted"""
     angles = np.array([0.5, 0.25, 0.75])  # n=1: c0, c1, c2
