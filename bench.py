@@ -41,7 +41,8 @@ N_SAMPLES = 1_000_000  # BASELINE.json configs[1] / [2]
 BYTES_PER_SAMPLE_PASS = {0: 24, 1: 24, 2: 32}  # 2 (Ward: 3) planes + measurement, fp64
 MODEL_NAME = {0: "phong", 1: "blinn-phong", 2: "ward"}
 P_TOL, E_TOL = 1e-5, 1e-8  # BASELINE.json north_star / SURVEY.md section 8d
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")  # rocprofv3 PMC records of scripts/profile_round.sh (traffic and VALU instructions)
+VALU_PEAK_LANE_INSTR_S = 256 * 4 * 16 * 2.4e9  # fp64 VALU issue: 256 CUs x 4 SIMDs x 16 lanes per clock x 2.4 GHz = 3.93e13 lane-instructions/s
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -120,7 +121,9 @@ def cpu_baseline_batched(method, model, n, total, budget_s=10.0):
     fits = sum(o["fits"] for o in outs)
     evals = sum(o["evals"] for o in outs)
     busy = max(o["secs"] for o in outs)
-    return {"value": evals / busy, "unit": "residual-evals/s", "cores": cores, "kind": outs[0]["kind"], "fits_per_s": fits / busy,
+    return {"value": evals / busy, "unit": "residual-evals/s", "cores": cores, "nproc": os.cpu_count(), "kind": outs[0]["kind"], "fits_per_s": fits / busy,
+            "cores_note": "worker processes = min(cores this job may use, 16 per visible GPU: the CPU share of one GPU of a shared node); "
+                          "BRDF_BENCH_CPU_WORKERS=all lifts the cap to every usable core, BRDF_BENCH_CPU_WORKERS=k sets it",
             "sample": f"{fits} of the workload's {total} surfels (surfel w, w+{cores}, ... on worker w), {cores} worker processes x "
                       f"{budget_s:.0f} s, one fit after the other per worker as in the reference's pixel loop (brdfdata.cpp:1195-1220), gcc -O2"}
 
@@ -130,8 +133,8 @@ def cpu_baseline_batched(method, model, n, total, budget_s=10.0):
 # ---------------------------------------------------------------------------------------------------------------------
 def host_cores():
     """worker processes of the all-core CPU baseline = the host cores this job may really use: the scheduler affinity, cut
-    down by a cgroup CPU quota if there is one, by BRDF_BENCH_CPU_WORKERS if set, and by 16 per visible GPU (the CPU
-    share that comes with one GPU of a shared node)"""
+    down by a cgroup CPU quota if there is one, by BRDF_BENCH_CPU_WORKERS if set (`all` = no further cap), and otherwise by
+    16 per visible GPU (the CPU share that comes with one GPU of a shared node)"""
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
@@ -139,8 +142,11 @@ def host_cores():
             cores = min(cores, max(1, -(-int(quota) // int(period))))
     except (OSError, ValueError):
         pass
-    if os.environ.get("BRDF_BENCH_CPU_WORKERS"):
-        return max(1, min(cores, int(os.environ["BRDF_BENCH_CPU_WORKERS"])))
+    want = os.environ.get("BRDF_BENCH_CPU_WORKERS")
+    if want == "all":  # BASELINE.md section 3's literal "all host cores": every core the job may use, no per-GPU share
+        return max(1, cores)
+    if want:
+        return max(1, min(cores, int(want)))
     try:
         import torch
         gpus = max(1, torch.cuda.device_count())  # (counting devices does not initialise the GPU)
@@ -171,6 +177,40 @@ def profiled_traffic(kernel):
         return tj["kernels"][kernel]["hbm_bytes_per_launch"], f"{os.path.relpath(TRAFFIC_FILE, ROOT)} ({tj.get('tag')}), sources {tj.get('source_hash')}"
     except (OSError, KeyError, ValueError) as exc:
         return None, f"no profiled traffic: {exc}"
+
+
+def alu_roofline(kernel, evals_per_s, evals_per_launch):
+    """the roof the resident / batched kernels really sit under: fp64 VALU issue.  valu_lane_instr_per_eval = rocprofv3
+    SQ_INSTS_VALU of one launch of `kernel` (wave instructions, x 64 lanes; every VALU instruction of the launch: sweeps,
+    reductions, the LM steps) / the residual evaluations of that launch, measured on the sources this library was built
+    from (else None); achieved = evals/s x that; peak = 3.93e13 lane-instr/s, the issue rate of fp64 instructions (32-bit
+    VALU instructions issue twice as fast, so the fraction is an upper bound of the issue time in use)"""
+    out = {"valu_lane_instr_per_eval": None, "achieved_instr_per_s": None, "peak": VALU_PEAK_LANE_INSTR_S, "unit": "lane-instr/s", "frac": None}
+    try:
+        tj = json.load(open(TRAFFIC_FILE))
+        if tj.get("source_hash") != source_hash():
+            out["source"] = f"{os.path.relpath(TRAFFIC_FILE, ROOT)} was measured on sources {tj.get('source_hash')}, this build is {source_hash()}"
+            return out
+        per_launch = tj["kernels"][kernel]["valu_wave_instr_per_launch"] * 64.0
+        out["valu_lane_instr_per_eval"] = per_launch / evals_per_launch
+        out["achieved_instr_per_s"] = evals_per_s * out["valu_lane_instr_per_eval"]
+        out["frac"] = out["achieved_instr_per_s"] / VALU_PEAK_LANE_INSTR_S
+        out["source"] = f"rocprofv3 --pmc SQ_INSTS_VALU, {os.path.relpath(TRAFFIC_FILE, ROOT)} ({tj.get('tag')}), sources {tj.get('source_hash')}"
+    except (OSError, KeyError, ValueError, TypeError) as exc:
+        out["source"] = f"no profiled instruction count: {exc}"
+    return out
+
+
+def batched_kernel_name(model, method, n):
+    """the kernel brdf_hip_fit_batch_dev runs for fits of n samples (batch_fit.hip: geometry by fit size), as rocprofv3 names it"""
+    m = {0: 0, 1: 1, 2: 1, 3: 2}[method]
+    if n <= 16:
+        return f"lane_fit_kernel<{model}, true, 1>" if method == 1 else f"rows_fit_kernel<{model}, {m}, true>"
+    if n <= 256:
+        return f"batch_fit_kernel<{model}, {m}, true, 64, 4>"
+    if n <= 1024:
+        return f"batch_fit_kernel<{model}, {m}, true, 256, 4>"
+    return f"resident_fit_kernel<{model}, {m}, true, true>"
 
 
 def _free_port():
@@ -240,20 +280,39 @@ def dist_setup(args):
 # ---------------------------------------------------------------------------------------------------------------------
 # c4 / c5: multi-surfel workloads
 # ---------------------------------------------------------------------------------------------------------------------
-def main_batched(args):
+def batched_cpu_subset(workload, entry, count=64):
+    """parity leg of a multi-surfel line: the CPU oracle's fits of the first `count` surfels (numpy + ctypes, before the
+    process touches the GPU); returns (p[count,3], info[count,10], ret[count])"""
     from brdf_amd import synth
-    S, n = {"c4": (65536, 4096), "c5": (1 << 20, 256)}[args.workload]
+    S, n = {"c4": (65536, 4096), "c5": (1 << 20, 256)}[workload]
+    model, method = 2, (0 if entry == "dif" else 1)
+    lib, fn, kind = _cpu_lib()
+    D = C.POINTER(C.c_double)
+    lb, ub = synth.bounds(model)
+    o, l, u = (np.array(v, dtype=np.float64) for v in (synth.OPTS, lb, ub))
+    angles, x, _ = synth.make_surfels(model, n, first=0, count=count)
+    ps, infos, rets = np.zeros((count, 3)), np.zeros((count, 10)), np.zeros(count, dtype=np.int64)
+    for s_ in range(count):
+        p = np.array(synth.P0[model], dtype=np.float64)
+        a = np.ascontiguousarray(angles[s_].reshape(-1))
+        xs = np.ascontiguousarray(x[s_])
+        rets[s_] = getattr(lib, fn)(method, model, a.ctypes.data_as(D), xs.ctypes.data_as(D), n, p.ctypes.data_as(D), synth.ITMAX,
+                                    o.ctypes.data_as(D), l.ctypes.data_as(D), u.ctypes.data_as(D), infos[s_].ctypes.data_as(D))
+        ps[s_] = p
+    return {"p": ps, "info": infos, "ret": rets, "kind": kind}
+
+
+def batched_line(args, workload, entry, ctx, steps, warmup, cpu_base=None, cpu_subset=None):
+    """one multi-surfel workload (c4 / c5) on the ranks of `ctx`; returns rank 0's line (None elsewhere)"""
+    from brdf_amd import synth
+    torch, dist, rank, world, backend, dev, stub = ctx
+    S, n = {"c4": (65536, 4096), "c5": (1 << 20, 256)}[workload]
     if args.surfels:
         S = args.surfels
     if args.samples:
         n = args.samples
-    model, method = 2, (0 if args.entry == "dif" else 1)
+    model, method = 2, (0 if entry == "dif" else 1)
     lb, ub = synth.bounds(model)
-    cpu_base = None
-    if (not args.no_cpu and int(os.environ.get("WORLD_SIZE", "1")) == 1 and os.environ.get("BRDF_BENCH_STUB") != "1"):
-        # before this process touches the GPU: the workers are plain child processes (numpy + ctypes, no torch, no HIP)
-        cpu_base = cpu_baseline_batched(method, model, n, S)
-    torch, dist, rank, world, backend, dev, stub = dist_setup(args)
     from brdf_amd import dist as bdist
     first, count = bdist.shard_range(S, rank, world)
     if stub:
@@ -283,14 +342,20 @@ def main_batched(args):
             rows = rows.cpu()
         return bdist.gather_results(rows, S, force=FORCE_COLL)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         one_step()
     if world > 1 or FORCE_COLL:
         dist.barrier()
     sync()
+    ev = None
+    if not stub:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         out = one_step()
+    if ev:
+        ev[1].record()
     if world > 1 or FORCE_COLL:
         dist.barrier()
     sync()
@@ -298,30 +363,77 @@ def main_batched(args):
     wt = torch.tensor([wall], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1 or FORCE_COLL:
         dist.all_reduce(wt, op=dist.ReduceOp.MAX)
+    line = None
     if rank == 0:
         wall = float(wt.item())
         nfev = float(out[:, 3 + 7].sum().item())
         failed = int((out[:, 13] < 0).sum().item())
         min_traffic = S * n * 32 + S * 104
-        line = {"metric": "BRDF residual-evals/sec (Ward 3-param, multi-surfel), whole job", "value": nfev * n * args.steps / wall,
-                "unit": "residual-evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": 1e3 * wall / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        evals_per_s = nfev * n * steps / wall
+        kernel = batched_kernel_name(model, method, n)
+        line = {"metric": "BRDF residual-evals/sec (Ward 3-param, multi-surfel), whole job", "value": evals_per_s,
+                "unit": "residual-evals/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+                "ms_per_step": 1e3 * wall / steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                 "dtype": "f64", "data": "synthetic",
-                "config": {"workload": f"BASELINE.json configs[{3 if args.workload == 'c4' else 4}]: {S} independent surfels x {n} samples, "
-                                       f"Ward fit, dlevmar_{args.entry}, surfels sharded contiguously over the ranks, one RCCL gather per step",
-                           "surfels": S, "samples_per_surfel": n, "entry_point": "dlevmar_" + args.entry, "fits_per_s": S * args.steps / wall,
+                "config": {"workload": f"BASELINE.json configs[{3 if workload == 'c4' else 4}]: {S} independent surfels x {n} samples, "
+                                       f"Ward fit, dlevmar_{entry}, surfels sharded contiguously over the ranks, one RCCL gather per step",
+                           "surfels": S, "samples_per_surfel": n, "entry_point": "dlevmar_" + entry, "fits_per_s": S * steps / wall,
                            "mean_nfev": nfev / S, "failed_fits": failed},
-                "roofline": {"bound": "hbm", "achieved": min_traffic * args.steps / wall / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": min_traffic * args.steps / wall / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                             "note": "batched regime: the samples are read from HBM once per fit (min_traffic = 32 B x n x S + 104 B per fit) "
-                                     "and the LM iterations run out of registers; the kernel is bound by fp64 VALU issue and the serial LM step, "
-                                     "not by HBM (DESIGN.md section 4)"}}
+                "roofline": {"bound": "fp64-valu", "kernel": "brdf::" + kernel,
+                             "alu": alu_roofline(kernel, evals_per_s / world, nfev * n / world),
+                             "hbm": {"achieved": min_traffic * steps / wall / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": min_traffic * steps / wall / 1e9 / HBM_PEAK_GBS, "min_traffic_bytes_per_step": min_traffic},
+                             "traffic": None,
+                             "note": "batched regime: the samples are read from HBM once per fit (hbm.min_traffic = 32 B x n x S + 104 B per fit) "
+                                     "and the LM iterations run out of registers, so the HBM fraction is small by construction; the binding roof is "
+                                     "fp64 VALU issue (alu: lane-instructions per second against 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz) and the "
+                                     "serial LM step of one wave per fit (DESIGN.md section 4)"}}
+        r = line["roofline"]
+        r["achieved"], r["peak"], r["unit"], r["frac"] = (r["alu"]["achieved_instr_per_s"], r["alu"]["peak"], "lane-instr/s", r["alu"]["frac"]) \
+            if r["alu"]["frac"] is not None else (r["hbm"]["achieved"], HBM_PEAK_GBS, "GB/s", r["hbm"]["frac"])
+        if r["alu"]["frac"] is None:
+            r["bound"] = "hbm"
+        if ev:
+            line["event_ms_per_step"] = ev[0].elapsed_time(ev[1]) / steps
         # the gathered rows (p, info, ret of every surfel, in surfel order) as one digest: runs on 1, 2, 4, 8 ranks must agree bit for bit
         line["result_sha256"] = hashlib.sha256(out.cpu().contiguous().numpy().tobytes()).hexdigest()[:16]
         if stub:
             line["stub_checksum"] = float(out[:, :3].sum().item())
         if cpu_base is not None:
             line["cpu_baseline"] = cpu_base
+        if cpu_subset is not None:  # parity on the surfels the CPU leg fitted: SURVEY.md section 8d's bar on those that converge on both sides
+            k = cpu_subset["p"].shape[0]
+            got = out[:k].cpu().numpy()
+            both = (cpu_subset["ret"] >= 0) & (got[:, 13] >= 0) & (cpu_subset["info"][:, 6] != 3) & (got[:, 3 + 6] != 3)
+            pc, pg = cpu_subset["p"][both], got[both, :3]
+            if method == 0:  # the unconstrained fit may land on -alpha (the model depends on alpha^2): compare |alpha|
+                pc, pg = np.abs(pc), np.abs(pg)
+            rel = np.max(np.abs(pg - pc) / np.maximum(np.abs(pc), 1e-12), axis=1)
+            rel_e = np.abs(got[both, 3 + 1] - cpu_subset["info"][both, 1]) / cpu_subset["info"][both, 1]
+            line["parity"] = {"surfels_compared": int(both.sum()), "of": int(k), "cpu": cpu_subset["kind"],
+                              "max_rel_err_params_vs_cpu_levmar": float(rel.max()) if rel.size else None,
+                              "max_rel_err_sumsq": float(rel_e.max()) if rel_e.size else None, "tolerance": P_TOL, "tolerance_sumsq": E_TOL,
+                              "ok": bool(rel.size > 0 and rel.max() <= P_TOL and rel_e.max() <= E_TOL)}
+    del angles, x, p0
+    if not stub:
+        torch.cuda.empty_cache()
+    return line
+
+
+def main_batched(args):
+    cpu_base = None
+    method = 0 if args.entry == "dif" else 1
+    S, n = {"c4": (65536, 4096), "c5": (1 << 20, 256)}[args.workload]
+    cpu_subset = None
+    if (not args.no_cpu and int(os.environ.get("WORLD_SIZE", "1")) == 1 and os.environ.get("BRDF_BENCH_STUB") != "1"):
+        # before this process touches the GPU: the workers are plain child processes (numpy + ctypes, no torch, no HIP)
+        cpu_base = cpu_baseline_batched(method, 2, args.samples or n, args.surfels or S)
+        if not args.surfels and not args.samples:
+            cpu_subset = batched_cpu_subset(args.workload, args.entry)
+    ctx = dist_setup(args)
+    torch, dist, rank, world = ctx[0], ctx[1], ctx[2], ctx[3]
+    line = batched_line(args, args.workload, args.entry, ctx, args.steps, args.warmup, cpu_base, cpu_subset)
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1 or FORCE_COLL:
         dist.destroy_process_group()
@@ -331,18 +443,21 @@ def main_batched(args):
 # ---------------------------------------------------------------------------------------------------------------------
 # c2 / c3: one large fit per GPU
 # ---------------------------------------------------------------------------------------------------------------------
-def main_single(args, model):
+def single_cpu_refs(model, angles, x, timed=True):
+    """CPU legs of a single-fit line (the reference's levmar on one host core), before the process touches the GPU.  timed:
+    the cpu_baseline of the headline (10-20 s); otherwise one fit per entry point, for the parity figures only"""
     from brdf_amd import synth
-    rank0_cpu = {}
-    rank_env = int(os.environ.get("RANK", "0"))
     p0, opts, lb, ub, itmax = synth.P0[model], synth.OPTS, synth.LB, synth.UB, synth.ITMAX
-    angles, x, truth = synth.make_single(model, N_SAMPLES, seed=synth.SEED + 7919 * rank_env)
-    if not args.no_cpu and rank_env == 0 and int(os.environ.get("WORLD_SIZE", "1")) == 1:
-        # CPU legs first, before this process has touched the GPU (they are never inside a timed region either way)
-        rank0_cpu["dif"] = cpu_baseline(0, model, angles, x, p0, opts, lb, ub, itmax)
-        rank0_cpu["bc_dif"] = cpu_baseline(1, model, angles, x, p0, opts, lb, ub, itmax, budget_s=6.0)
+    return {"dif": cpu_baseline(0, model, angles, x, p0, opts, lb, ub, itmax, budget_s=12.0 if timed else 0.0),
+            "bc_dif": cpu_baseline(1, model, angles, x, p0, opts, lb, ub, itmax, budget_s=6.0 if timed else 0.0)}
 
-    torch, dist, rank, world, backend, dev, stub = dist_setup(args)
+
+def single_line(args, model, ctx, steps, warmup, angles, x, rank0_cpu):
+    """one single-material workload (c2 / c3): every rank fits its own material `steps` times through both entry points;
+    returns (rank 0's line or None, exit code)"""
+    from brdf_amd import synth
+    torch, dist, rank, world, backend, dev, stub = ctx
+    p0, opts, lb, ub, itmax = synth.P0[model], synth.OPTS, synth.LB, synth.UB, synth.ITMAX
     import brdf_amd
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
     # each rank owns one material: same generator, different seed -> different planes and noise
@@ -405,14 +520,19 @@ def main_single(args, model):
 
     out = {}
     for method, name in ((0, "dif"), (1, "bc_dif")):
-        allstat, results = run(method, args.steps, args.warmup)
+        allstat, results = run(method, steps, warmup)
         wall = float(allstat[:, 0].max())  # max over ranks
         evals = float(allstat[:, 1].sum())  # whole job
         r0 = results[0]
+        nfev, njev = float(r0[0, 10]), float(r0[0, 11])
+        # the streaming visits of the samples the REFERENCE makes for this fit (N_jac_passes + N_trial_passes):
+        # one per Jacobian (levmar counts it as m, bc: m + 1, evaluations in nfev) and one per other evaluation
+        ref_passes = njev + (nfev - (3.0 if method == 0 else 4.0) * njev)
         out[name] = {
-            "value": evals / wall, "ms_per_step": 1e3 * wall / args.steps, "evals_per_step_rank0": float(r0[0, 10]) * N_SAMPLES,
-            "nfev": float(r0[0, 10]), "iters": float(r0[0, 8]), "passes_per_step": float(allstat[0, 3]) / args.steps,
-            "event_ms_rank0": float(allstat[0, 2]), "device_us_per_step": float(allstat[0, 5]) / args.steps,
+            "value": evals / wall, "ms_per_step": 1e3 * wall / steps, "evals_per_step_rank0": nfev * N_SAMPLES,
+            "nfev": nfev, "njev": njev, "iters": float(r0[0, 8]), "passes_per_step": float(allstat[0, 3]) / steps,
+            "reference_passes_per_step": ref_passes,
+            "event_ms_rank0": float(allstat[0, 2]), "device_us_per_step": float(allstat[0, 5]) / steps,
             "p": [float(v) for v in r0[0, :3]], "sumsq": float(r0[0, 4]),
             # HIP-event time of the fits (one event pair per fit, summed over the timed region) / ALL launches of the
             # pass kernel in them (launch chain: the passes plus the few run-ahead launches per fit that find it finished):
@@ -420,32 +540,40 @@ def main_single(args, model):
             # with the host's gaps between two fits
             "avg_launch_us": 1e3 * float(allstat[0, 7]) / max(1.0, float(allstat[0, 6])),
             "region_us_per_launch": 1e3 * float(allstat[0, 2]) / max(1.0, float(allstat[0, 6])),
-            "launches_per_step": float(allstat[0, 6]) / args.steps,
+            "launches_per_step": float(allstat[0, 6]) / steps,
             # device clock (s_memrealtime) from the first to the finishing pass / passes: sweeping launches only
             "avg_sweeping_launch_us": float(allstat[0, 5]) / max(1.0, float(allstat[0, 3])),
         }
-
+    del a_dev, x_dev
     if rank != 0:
-        if world > 1 or FORCE_COLL:
-            dist.destroy_process_group()
-        return 0
+        return None, 0
 
     bpsp = BYTES_PER_SAMPLE_PASS[model]
 
     def roofline_of(head, method):
-        # The dominant kernel.  Resident regime (default when the fit fits the chip): ONE launch per fit, the launch performs
-        # passes_per_fit sweeps over samples it read from HBM once.  Launch chain: one launch per sweep.
+        # The dominant kernel.  Resident regime (default when the fit fits the chip): ONE launch per fit.  Launch chain: one launch
+        # per sweep.  Algorithmic bytes by SURVEY.md section 8d: bytes per sample-pass x n x the passes of the REFERENCE algorithm
+        # (reference_passes: one per Jacobian, one per other evaluation; identical to levmar's own counts in info[7], info[8]).
+        # The launch serves them with FEWER sweeps over its resident samples (a chain of rejected trial points shares one sweep; a
+        # candidate that is taken brings the next iteration's Jacobian with it): sweeps_per_launch and the fraction by executed
+        # sweeps are reported next to it.
         resident = head["launches_per_step"] < 1.5
         kernel = f"resident_fit_kernel<{model}, {method}, true, false>" if resident else f"stream_pass<{model}, {method}, true>"
         traffic, traffic_src = profiled_traffic(kernel)
         sweeps_per_launch = head["passes_per_step"] if resident else 1.0
-        bytes_per_launch = bpsp * N_SAMPLES * sweeps_per_launch
+        ref_per_launch = head["reference_passes_per_step"] if resident else head["reference_passes_per_step"] / max(1.0, head["passes_per_step"])
+        bytes_per_launch = bpsp * N_SAMPLES * ref_per_launch
         achieved = bytes_per_launch / (head["avg_launch_us"] * 1e-6) / 1e9
+        by_sweeps = bpsp * N_SAMPLES * sweeps_per_launch / (head["avg_launch_us"] * 1e-6) / 1e9
+        evals_per_launch = head["evals_per_step_rank0"] / max(1.0, head["launches_per_step"])
         r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
              "traffic": traffic, "traffic_source": traffic_src, "kernel": "brdf::" + kernel, "regime": "resident" if resident else "launch chain",
-             "algorithmic_bytes_per_launch": bytes_per_launch, "sweeps_per_launch": sweeps_per_launch,
+             "algorithmic_bytes_per_launch": bytes_per_launch, "reference_passes_per_launch": ref_per_launch,
+             "sweeps_per_launch": sweeps_per_launch, "achieved_by_executed_sweeps": by_sweeps, "frac_by_executed_sweeps": by_sweeps / HBM_PEAK_GBS,
              "avg_launch_us": head["avg_launch_us"], "region_us_per_launch": head["region_us_per_launch"],
-             "avg_sweeping_launch_us": head["avg_sweeping_launch_us"], "launches_per_step": head["launches_per_step"]}
+             "avg_sweeping_launch_us": head["avg_sweeping_launch_us"], "launches_per_step": head["launches_per_step"],
+             "alu": alu_roofline(kernel, head["evals_per_step_rank0"] / (head["avg_launch_us"] * 1e-6 * max(1.0, head["launches_per_step"])),
+                                 evals_per_launch)}
         if traffic is not None:  # what really crosses the HBM interface: the samples are read ONCE per resident fit
             r["hbm_measured_gbs"] = traffic / (head["avg_launch_us"] * 1e-6) / 1e9
         return r
@@ -453,31 +581,36 @@ def main_single(args, model):
     head = out["dif"]
     roof = roofline_of(head, 0)
     roof["note"] = (
-        f"achieved = SURVEY.md section 8d's algorithmic bytes ({bpsp} B per sample per LM evaluation: "
-        f"{'3' if model == 2 else '2'} planes + measurement, fp64) x 1e6 samples x the launch's evaluations (sweeps_per_launch) / the "
+        f"achieved = SURVEY.md section 8d's algorithmic bytes ({bpsp} B per sample-pass: "
+        f"{'3' if model == 2 else '2'} planes + measurement, fp64) x 1e6 samples x the passes of the reference algorithm for this fit "
+        "(reference_passes_per_launch = one per Jacobian + one per other evaluation, from info[7] / info[8]) / the "
         "average HIP-event time of a fit's launch (one event pair per fit on the launch stream); in the "
-        "resident regime one launch is a whole fit: the in-launch exchanges and serial LM steps are part of it.  region_us_per_launch "
-        "adds the host's gap between two fits; avg_sweeping_launch_us = device clock per evaluation.  traffic = HBM-side bytes per "
-        "launch from rocprofv3 FETCH_SIZE (x2 gfx950 correction, calibrated) + WRITE_SIZE, valid only for the sources named in "
-        "traffic_source: the samples are read ONCE per fit, so the measured traffic (hbm_measured_gbs) is ~1/sweeps of the algorithmic "
-        "figure -- the launch is bound by the exchange + LM step latency and by fp64 issue, not by HBM bandwidth (DESIGN.md section 4)")
+        "resident regime one launch is a whole fit: the in-launch exchanges and serial LM steps are part of it.  The launch makes "
+        "sweeps_per_launch sweeps over its resident samples for them (shared sweeps: DESIGN.md section 2); frac_by_executed_sweeps counts "
+        "those instead.  region_us_per_launch adds the host's gap between two fits; avg_sweeping_launch_us = device clock per sweep.  "
+        "traffic = HBM-side bytes per launch from rocprofv3 FETCH_SIZE (x2 gfx950 correction, calibrated) + WRITE_SIZE, valid only for "
+        "the sources named in traffic_source: the samples are read ONCE per fit, so the measured traffic (hbm_measured_gbs) is a small "
+        "fraction of the algorithmic figure -- the launch is bound by the exchange + LM step latency and by fp64 issue (alu), not by "
+        "HBM bandwidth (DESIGN.md section 4)")
     line = {
         "metric": f"BRDF residual-evals/sec (1 M samples, {MODEL_NAME[model].title()} 3-param), whole job; rel-err vs CPU levmar in `parity`",
         "value": head["value"], "unit": "residual-evals/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": head["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"BASELINE.json configs[{1 if model == 2 else 2}]: single-material {MODEL_NAME[model]} 3-param fit, 1,000,000 synthetic samples, "
                                f"dlevmar_dif (FD Jacobian + Broyden), p0={{{', '.join(str(v) for v in p0)}}}, opts={{1e-3,1e-15,1e-15,1e-20,1e-6}}, itmax=100; "
                                "one step = one complete fit, samples resident in HBM when the timed region starts; one material per GPU",
                    "n_samples": N_SAMPLES, "brdf": MODEL_NAME[model], "entry_point": "dlevmar_dif", "fits_per_step_per_gpu": 1,
-                   "nfev_per_fit": head["nfev"], "lm_iterations": head["iters"], "passes_per_fit": head["passes_per_step"]},
+                   "nfev_per_fit": head["nfev"], "lm_iterations": head["iters"], "reference_passes_per_fit": head["reference_passes_per_step"],
+                   "passes_per_fit": head["passes_per_step"]},
         "roofline": roof,
         "fitted_params": head["p"], "sumsq": head["sumsq"],
-        "bc_dif": {k: out["bc_dif"][k] for k in ("value", "ms_per_step", "nfev", "iters", "passes_per_step", "launches_per_step", "avg_launch_us",
-                                                    "avg_sweeping_launch_us", "p")},
+        "bc_dif": {k: out["bc_dif"][k] for k in ("value", "ms_per_step", "nfev", "njev", "iters", "reference_passes_per_step", "passes_per_step",
+                                                    "launches_per_step", "avg_launch_us", "avg_sweeping_launch_us", "p")},
     }
     line["bc_dif"]["roofline"] = {k: v for k, v in roofline_of(out["bc_dif"], 1).items()
-                                  if k in ("achieved", "frac", "traffic", "traffic_source", "kernel", "algorithmic_bytes_per_launch", "avg_launch_us")}
+                                  if k in ("achieved", "frac", "traffic", "traffic_source", "kernel", "algorithmic_bytes_per_launch", "avg_launch_us",
+                                           "reference_passes_per_launch", "sweeps_per_launch", "frac_by_executed_sweeps", "alu")}
     rc = 0
     if rank0_cpu:
         base, p_cpu, info_cpu = rank0_cpu["dif"]
@@ -495,7 +628,54 @@ def main_single(args, model):
         if not ok:  # a fast number with a wrong answer is not a result
             print("bench.py: PARITY FAILURE against the CPU levmar path", file=sys.stderr)
             rc = 3
-    print(json.dumps(line), flush=True)
+    return line, rc
+
+
+def main_single(args, model):
+    """c2 / c3.  The default run (`python bench.py`: c2 on one GPU) also carries the other BASELINE.json configurations as
+    short sub-lines under `configs`: c3 through both entry points, c4 and c5 through dlevmar_dif -- a few steps each, parity
+    against single CPU fits (c3) or the CPU fits of the first 64 surfels (c4 / c5) instead of the timed CPU baselines, which
+    the explicit `--workload` runs keep."""
+    from brdf_amd import synth
+    rank_env = int(os.environ.get("RANK", "0"))
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    angles, x, truth = synth.make_single(model, N_SAMPLES, seed=synth.SEED + 7919 * rank_env)
+    with_cpu = not args.no_cpu and rank_env == 0 and world_env == 1
+    subs = args.workload == "c2" and args.gpus == 1 and world_env == 1 and not args.headline_only and os.environ.get("BRDF_BENCH_STUB") != "1"
+    # CPU legs first, before this process has touched the GPU (they are never inside a timed region either way)
+    rank0_cpu = single_cpu_refs(model, angles, x) if with_cpu else {}
+    sub_cpu = {}
+    if subs:
+        a3, x3, _ = synth.make_single(1, N_SAMPLES, seed=synth.SEED)
+        sub_cpu["c3"] = (a3, x3, single_cpu_refs(1, a3, x3, timed=False) if with_cpu else {})
+        for wl in ("c4", "c5"):
+            sub_cpu[wl] = batched_cpu_subset(wl, "dif") if with_cpu else None
+    ctx = dist_setup(args)
+    torch, dist, rank, world = ctx[0], ctx[1], ctx[2], ctx[3]
+    line, rc = single_line(args, model, ctx, args.steps, args.warmup, angles, x, rank0_cpu)
+    if rank == 0 and subs:
+        configs = {}
+        try:
+            a3, x3, refs3 = sub_cpu["c3"]
+            l3, rc3 = single_line(args, 1, ctx, 10, 2, a3, x3, refs3)
+            keep = ("value", "ms_per_step", "steps", "config", "roofline", "fitted_params", "sumsq", "bc_dif", "parity")
+            configs["c3"] = {k: l3[k] for k in keep if k in l3}
+            for part in (configs["c3"], configs["c3"].get("bc_dif", {})):
+                part.pop("cpu_baseline", None)  # (one untimed CPU fit per entry point: a parity reference, not a baseline)
+            rc = rc or rc3
+            for wl in ("c4", "c5"):
+                lb_ = batched_line(args, wl, "dif", ctx, 2, 1, None, sub_cpu[wl])
+                configs[wl + "_dif"] = {k: lb_[k] for k in ("value", "ms_per_step", "steps", "config", "roofline", "result_sha256", "parity",
+                                                           "event_ms_per_step") if k in lb_}
+                if "parity" in lb_ and not lb_["parity"]["ok"]:
+                    print(f"bench.py: PARITY FAILURE in the {wl} sub-line", file=sys.stderr)
+                    rc = rc or 3
+        except Exception as exc:  # noqa: BLE001  (a sub-line must never cost the headline)
+            configs["error"] = f"{type(exc).__name__}: {exc}"
+            rc = rc or 4
+        line["configs"] = configs
+    if rank == 0:
+        print(json.dumps(line), flush=True)
     if world > 1 or FORCE_COLL:
         dist.destroy_process_group()
     return rc
@@ -511,6 +691,7 @@ def main():
                     help="c2 (default, the benchmarked configuration): BASELINE.json configs[1] (Ward); c3: configs[2] (Blinn-Phong); "
                          "c4 / c5: configs[3] / [4], the multi-surfel configurations, surfels sharded over the ranks (strong scaling)")
     ap.add_argument("--entry", default="dif", choices=["dif", "bc_dif"], help="entry point for c4 / c5")
+    ap.add_argument("--headline-only", action="store_true", help="c2 on one GPU without the configs[2..4] sub-lines")
     ap.add_argument("--surfels", type=int, default=0, help=argparse.SUPPRESS)  # rehearsal / tests: shrink c4 / c5
     ap.add_argument("--samples", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()

@@ -38,11 +38,12 @@ if t:
         real = [x for x in v if x > 5000]  # launches that did a sweep (run-ahead launches after the fit ended return at once)
         print(f"{k:45s} calls {len(v):6d} total {sum(v)/1e6:9.3f} ms  avg {st.mean(v):9.0f}  median {st.median(v):9.0f}  "
               f"min {min(v):7d} max {max(v):8d} | sweeping launches: {len(real)} avg {st.mean(real) if real else 0:9.0f}")
-for sub, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE"), ("cal_fetch", "FETCH_SIZE"), ("cal_write", "WRITE_SIZE")):
+for sub, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE"), ("cal_fetch", "FETCH_SIZE"), ("cal_write", "WRITE_SIZE"),
+                     ("pmc_valu", "SQ_INSTS_VALU"), ("pmc_valu", "SQ_ACTIVE_INST_VALU"), ("pmc_valu", "SQ_WAVE_CYCLES"), ("pmc_valu", "SQ_BUSY_CYCLES")):
     p = find(sub, "*counter_collection.csv")
     if not p:
         continue
-    print(f"== {counter} per launch, KiB as reported ({sub}) ==")
+    print(f"== {counter} per launch, as reported ({sub}; FETCH/WRITE_SIZE in KiB) ==")
     for k, v in sorted(pmc_stats(p, counter).items(), key=lambda kv: -sum(kv[1])):
         big = [x for x in v if x > 0.05 * max(v)] if max(v) > 0 else v
         print(f"{k:45s} launches {len(v):6d} mean {st.mean(v):12.1f} median {st.median(v):12.1f} max {max(v):12.1f} | non-trivial launches: {len(big)} mean {st.mean(big):12.1f}")
@@ -68,6 +69,10 @@ if len(sys.argv) > 3 and sys.argv[2] == "--traffic-json":
     kw = next((v for k, v in cal_w.items() if "model_eval_kernel<2>" in k), None)
     fcorr = (3 * 512 * 1024) / st.mean(kf) if kf else 2.0
     wcorr = (512 * 1024) / st.mean(kw) if kw else 1.0
+    pv = find("pmc_valu", "*counter_collection.csv")
+    valu = pmc_stats(pv, "SQ_INSTS_VALU") if pv else {}
+    valu_busy = pmc_stats(pv, "SQ_ACTIVE_INST_VALU") if pv else {}
+    wave_cyc = pmc_stats(pv, "SQ_WAVE_CYCLES") if pv else {}
     kernels = {}
     for k, v in fetch.items():
         if "fit_kernel" not in k and "stream_pass" not in k:
@@ -77,8 +82,15 @@ if len(sys.argv) > 3 and sys.argv[2] == "--traffic-json":
         wbig = [x for x in w if x > 0.05 * max(w)] if max(w) > 0 else w
         kernels[k] = {"fetch_kib_reported": st.mean(big), "fetch_correction": fcorr, "write_kib_reported": st.mean(wbig), "write_correction": wcorr,
                       "hbm_bytes_per_launch": int(1024 * (st.mean(big) * fcorr + st.mean(wbig) * wcorr))}
+        if k in valu:  # VALU wave-instructions per (sweeping) launch: bench.py's roofline.alu
+            iv = valu[k]
+            ibig = [x for x in iv if x > 0.05 * max(iv)] if max(iv) > 0 else iv
+            kernels[k]["valu_wave_instr_per_launch"] = st.mean(ibig)
+            if k in valu_busy and k in wave_cyc:
+                kernels[k]["sq_active_inst_valu_per_launch"] = st.mean([x for x in valu_busy[k] if x > 0.05 * max(valu_busy[k])])
+                kernels[k]["sq_wave_cycles_per_launch"] = st.mean([x for x in wave_cyc[k] if x > 0.05 * max(wave_cyc[k])])
     json.dump({"tag": tag, "source_hash": h.hexdigest()[:16],
-               "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `python3 bench.py --steps 10 --warmup 2 --no-cpu` (scripts/profile_round.sh)",
+               "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_INSTS_VALU ... in separate passes over `python3 bench.py --steps 10 --warmup 2 --no-cpu` (scripts/profile_round.sh)",
                "calibration": f"scripts/calib_traffic.py: model_eval_kernel<2> reads 3 x 512 MiB / writes 512 MiB, 8 B per lane coalesced: FETCH_SIZE x {fcorr:.4f}, WRITE_SIZE x {wcorr:.4f}",
                "kernels": kernels}, open(out_path, "w"), indent=1)
     print("wrote", out_path)
