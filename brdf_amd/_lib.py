@@ -49,6 +49,10 @@ ABI = {
     "dlevmar_chkjac": (None, [C.c_void_p, C.c_void_p, D, C.c_int, C.c_int, C.c_void_p, D]),
     "brdf_hip_fit_dev": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, D, D, D, D, C.c_int, D, D, D,
                                    C.c_void_p]),
+    "brdf_hip_fit_channels_dev": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_int, D, D, D, D, C.c_int, D,
+                                            D, D, C.c_void_p]),
+    "brdf_hip_last_channels_stamps": (C.c_int, [C.c_int, C.POINTER(C.c_longlong)]),
+    "brdf_hip_last_channels_stats": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), D]),
     "brdf_hip_fit_batch_dev": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, D, D,
                                          C.c_int, D, C.c_void_p, C.c_void_p, C.c_void_p]),
     "brdf_hip_fit_batch": (C.c_int, [C.c_int, C.c_int, D, D, C.c_int, C.c_int, D, D, D, C.c_int, D, D, I]),

@@ -245,8 +245,9 @@ struct PassUniforms {
 };
 
 // f(p) for one (prepared) sample
-template <int MODEL, bool FAST>
-LM_HD double model_value(const PassUniforms<MODEL> &u, double c0, const Prep &q) {
+// (U: PassUniforms<MODEL>, or any struct with the fields a function reads -- channels_fit_impl.h keeps per-request copies in scalar registers)
+template <int MODEL, bool FAST, class U>
+LM_HD double model_value(const U &u, double c0, const Prep &q) {
   using Mdl = BrdfModel<MODEL>;
   return Mdl::combine(u.l0, c0, Mdl::template shape<FAST>(u.n0, c0, q));
 }
@@ -267,14 +268,16 @@ LM_HD double model_value_q(const PassUniforms<MODEL> &u, double c0, const Prep &
 
 // f(p) and one row of the finite-difference Jacobian.  `base` is the value subtracted in the forward
 // formula: f(p) recomputed (bc_dif, lmbc_core.c:1049) or the stored hx (dif, lm_core.c:580).
-template <int MODEL, bool FAST>
-LM_HD void model_fd_row(const PassUniforms<MODEL> &u, double c0, const Prep &q, bool need_f0, double &f0,
-                        double base_or_nan, bool use_base, double *jrow) {
+// CENTRAL as a template argument: no branch inside the row, so that a sweep that hoists the (request-uniform) choice out of its
+// sample loop gets straight-line sample bodies -- whose exp chains the scheduler can then interleave
+template <int MODEL, bool FAST, bool CENTRAL, class U>
+LM_HD void model_fd_row_t(const U &u, double c0, const Prep &q, bool need_f0, double &f0, double base_or_nan, bool use_base,
+                          double *jrow) {
   using Mdl = BrdfModel<MODEL>;
   const double s0 = Mdl::template shape<FAST>(u.n0, c0, q);
   if (need_f0) f0 = Mdl::combine(u.l0, c0, s0);
   const double sp = Mdl::template shape<FAST>(u.np2, c0, q);
-  if (!u.central) {
+  if (!CENTRAL) {
     const double base = use_base ? base_or_nan : f0;
     jrow[0] = (Mdl::combine(u.lp[0], c0, s0) - base) * u.dinv[0];
     jrow[1] = (Mdl::combine(u.lp[1], c0, s0) - base) * u.dinv[1];
@@ -286,10 +289,18 @@ LM_HD void model_fd_row(const PassUniforms<MODEL> &u, double c0, const Prep &q, 
     jrow[2] = (Mdl::combine(u.lp[2], c0, sp) - Mdl::combine(u.lm[2], c0, sm)) * u.dinv[2];
   }
 }
+template <int MODEL, bool FAST, class U>
+LM_HD void model_fd_row(const U &u, double c0, const Prep &q, bool need_f0, double &f0,
+                        double base_or_nan, bool use_base, double *jrow) {
+  if (!u.central)
+    model_fd_row_t<MODEL, FAST, false>(u, c0, q, need_f0, f0, base_or_nan, use_base, jrow);
+  else
+    model_fd_row_t<MODEL, FAST, true>(u, c0, q, need_f0, f0, base_or_nan, use_base, jrow);
+}
 
 // f(p) and one row of the analytic Jacobian (the caller's jacf of dlevmar_bc_der, lmbc_core.c:578, for a built-in model)
-template <int MODEL, bool FAST>
-LM_HD void model_an_row(const PassUniforms<MODEL> &u, double c0, const Prep &q, double &f0, double *jrow) {
+template <int MODEL, bool FAST, class U>
+LM_HD void model_an_row(const U &u, double c0, const Prep &q, double &f0, double *jrow) {
   using Mdl = BrdfModel<MODEL>;
   const double s = Mdl::template shape<FAST>(u.n0, c0, q);
   f0 = Mdl::combine(u.l0, c0, s);

@@ -512,6 +512,37 @@ int brdf_hip_fit_dev(int method, int model, const double *d_angles, const double
   return stream_fit_run(a);
 }
 
+int brdf_hip_fit_channels_dev(int method, int model, const double *d_angles, const double *d_x, long long x_stride, int n, int channels,
+                              double *p, const double *lb, const double *ub, const double *dscl, int itmax, const double *opts,
+                              double *info, double *covar, void *stream) {
+  if (!d_angles || !d_x || !p || n <= 0 || channels < 1 || channels > 16 || (channels > 1 && x_stride < n)) {
+    set_error("brdf_hip_fit_channels_dev(): bad arguments");
+    return LM_ERROR;
+  }
+  if (method < 0 || method > 3 || model < 0 || model >= MODEL_COUNT) {
+    set_error("brdf_hip_fit_channels_dev(): unknown method %d or model %d", method, model);
+    return LM_ERROR;
+  }
+  return channels_fit_run(method, model, d_angles, d_x, x_stride, n, channels, p, lb, ub, dscl, itmax, opts, info, covar,
+                          static_cast<hipStream_t>(stream));
+}
+
+/* diagnostic builds (-DBRDF_STAMPS) only: cycles per section of channel `channel`'s control wave, summed over its passes */
+int brdf_hip_last_channels_stamps(int channel, long long *out8) {
+  const FitStats st = channels_last_stats(channel);
+  for (int i = 0; i < 8; ++i) out8[i] = st.stamps[i];
+  return 0;
+}
+
+int brdf_hip_last_channels_stats(int channel, int *shared_launch, long long *passes, long long *jac_passes, double *device_us) {
+  const FitStats st = channels_last_stats(channel);
+  if (shared_launch) *shared_launch = channels_last_shared();
+  if (passes) *passes = st.passes;
+  if (jac_passes) *jac_passes = st.jac_passes;
+  if (device_us) *device_us = st.device_us;
+  return 0;
+}
+
 int brdf_hip_fit_batch_dev(int method, int model, const double *d_angles, const double *d_x, int S, int n,
                            double *d_p, const double *lb, const double *ub, int itmax, const double *opts,
                            double *d_info, int *d_ret, void *stream) {

@@ -348,28 +348,14 @@ int capture_fit_single_run(int model, const unsigned char *d_images, int L, int 
   hipLaunchKernelGGL(single_pack_kernel, dim3((unsigned)gb), dim3(kCT), 0, stream, d_images, L, H, W, pixel_list.as<long long>(),
                      angles_f.as<double>(), F, planes.as<double>(), x3.as<double>());
   CAP_OK(hipGetLastError());
-  int worst = 0;
-  for (int c = 0; c < 3; ++c) {  // "do the calculation once for each color-channel", brdfdata.cpp:1161
-    StreamFitArgs a;
-    a.method = 1;  // dlevmar_bc_dif, brdfdata.cpp:1058
-    a.model = model;
-    a.d_angles = planes.as<double>();
-    a.d_x = x3.as<double>() + (size_t)c * n;
-    a.n = (int)n;
-    double p[3] = {p0[0], p0[1], p0[2]};
-    a.p = p;
-    a.lb = lb;
-    a.ub = ub;
-    a.dscl = nullptr;
-    a.itmax = itmax;
-    a.opts = opts;
-    a.info = info ? info + 10 * c : nullptr;
-    a.covar = nullptr;
-    a.stream = stream;
-    const int r = stream_fit_run(a);
-    for (int k = 0; k < 3; ++k) single_brdf[3 * c + k] = p[k];
-    if (r < 0) worst = kLmError;
-  }
+  // "do the calculation once for each color-channel", brdfdata.cpp:1161: three dlevmar_bc_dif fits (:1058) over the SAME planes --
+  // one shared resident launch where the fit fits the chip (channels_fit_impl.h), one fit after the other otherwise
+  double p3[9];
+  for (int c = 0; c < 3; ++c)
+    for (int k = 0; k < 3; ++k) p3[3 * c + k] = p0[k];
+  const int worst = channels_fit_run(/*method=*/1, model, planes.as<double>(), x3.as<double>(), n, (int)n, 3, p3, lb, ub, nullptr, itmax, opts,
+                                     info, nullptr, stream);
+  for (int k = 0; k < 9; ++k) single_brdf[k] = p3[k];
   CAP_OK(hipStreamSynchronize(stream));
   return worst;
 }

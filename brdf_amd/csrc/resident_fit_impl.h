@@ -308,10 +308,11 @@ __device__ __forceinline__ constexpr bool slot_used(int v) { return v < NS || (M
 
 // val[j] <- slot 4j + lane/16 of column lane%16 of the block starting at cell `first` (0 where the slot is not used or
 // the column >= ncols)
-template <int NS, bool MAX = true>
-__device__ __forceinline__ bool gather_block(const ResidentCtx &ctx, __amdgpu_buffer_rsrc_t t, unsigned first, unsigned tag, int ncols,
+// (Ctx: ResidentCtx, or the per-channel view of channels_fit_impl.h -- anything with ctl, launch_id, spin_ticks)
+template <int NS, bool MAX = true, class Ctx>
+__device__ __forceinline__ bool gather_block(const Ctx &ctx, __amdgpu_buffer_rsrc_t t, unsigned first, unsigned tag, int ncols,
                                              double (&val)[4], unsigned *polls) {
-  const int lane = threadIdx.x;  // control wave = wave 0
+  const int lane = threadIdx.x & (kWave - 1);  // a control wave's lane (the single-fit kernel's control wave is wave 0)
   const int col = lane & 15, r = lane >> 4;
   const long long t0 = (long long)wall_clock64();
   for (unsigned spins = 0;; ++spins) {
@@ -347,7 +348,7 @@ __device__ __forceinline__ bool gather_block(const ResidentCtx &ctx, __amdgpu_bu
 // folds the 16 columns of every slot: the total of slot 4j + r ends in lane 16r + 15 of val[j] (the max slot by max)
 template <int NS, bool MAX>
 __device__ __forceinline__ void fold_block(double (&val)[4]) {
-  const int r = (int)threadIdx.x >> 4;
+  const int r = (int)(threadIdx.x & (kWave - 1)) >> 4;
   double mx = 0.0;
   if constexpr (MAX) mx = row_reduce_to_last<OpMax>(val[kSums / 4]);
 #pragma unroll
@@ -356,10 +357,10 @@ __device__ __forceinline__ void fold_block(double (&val)[4]) {
   if (MAX && r == (kSums & 3)) val[kSums / 4] = mx;
 }
 
-template <int NS, bool MAX = true>
-__device__ __forceinline__ bool control_exchange(const ResidentCtx &ctx, unsigned epoch, double *sums, int *s_abort,
+template <int NS, bool MAX = true, class Ctx>
+__device__ __forceinline__ bool control_exchange(const Ctx &ctx, unsigned epoch, double *sums, int *s_abort,
                                                  long long *st_, long long &last_) {
-  const int lane = threadIdx.x;  // control wave = wave 0
+  const int lane = threadIdx.x & (kWave - 1);  // a control wave's lane
   const int col = lane & 15, r = lane >> 4;
   const int G = gridDim.x;
   const int grp = blockIdx.x / kGroup, ngrp = (G + kGroup - 1) / kGroup;
@@ -482,17 +483,32 @@ __device__ __forceinline__ void sweep_pass(int kind, const PassUniforms<MODEL> &
     break;
   case RQ_JAC:
     if constexpr (METHOD != 0) {
-      for_bc([&](int k) {
-        double f0 = 0.0, j[kM];
-        if (u.analytic)  // dlevmar_bc_der / dlevmar_der with the model's analytic Jacobian
-          model_an_row<MODEL, FAST>(u, st.get(kFc0, k), prep(k), f0, j);
-        else
-          model_fd_row<MODEL, FAST>(u, st.get(kFc0, k), prep(k), true, f0, 0.0, false, j);
-        double e = st.get(kFx, k) - f0;
-        if (dead(k)) e = j[0] = j[1] = j[2] = 0.0;
-        acc_normal_eq_fma(j, e, acc, acc + kNL);
-        acc[kNL + kM] = fma(e, e, acc[kNL + kM]);
-      });
+      // The kind of row -- forward differences, central differences, the model's analytic Jacobian (dlevmar_bc_der / dlevmar_der)
+      // -- is the same for every sample of a pass: chosen HERE, not inside the sample body.  A branch in the body, uniform or not,
+      // splits its basic block between the row's two exp chains; in one block the scheduler interleaves them (measured with
+      // scripts/micro/exp_ilp.hip: a lone dependent exp chain takes 237 cycles per exp on a wave, two interleaved 110 each).
+      auto jac = [&](auto jk) {
+        constexpr int JK = decltype(jk)::value;
+        for_bc([&](int k) {
+          double f0 = 0.0, j[kM];
+          if (JK == 2)
+            model_an_row<MODEL, FAST>(u, st.get(kFc0, k), prep(k), f0, j);
+          else if (JK == 1)
+            model_fd_row_t<MODEL, FAST, true>(u, st.get(kFc0, k), prep(k), true, f0, 0.0, false, j);
+          else
+            model_fd_row_t<MODEL, FAST, false>(u, st.get(kFc0, k), prep(k), true, f0, 0.0, false, j);
+          double e = st.get(kFx, k) - f0;
+          if (dead(k)) e = j[0] = j[1] = j[2] = 0.0;
+          acc_normal_eq_fma(j, e, acc, acc + kNL);
+          acc[kNL + kM] = fma(e, e, acc[kNL + kM]);
+        });
+      };
+      if (u.analytic)
+        jac(std::integral_constant<int, 2>{});
+      else if (u.central)
+        jac(std::integral_constant<int, 1>{});
+      else
+        jac(std::integral_constant<int, 0>{});
     }
     break;
   case RQ_DIF_INIT:

@@ -87,6 +87,14 @@ bool resident_fit_try(const StreamFitArgs &a, int *ret);
 FitStats resident_fit_last_stats();
 int resident_fit_last_trace(long long *out, int max_rows);  // diagnostic builds: [workgroup][8] stamps of one epoch
 
+// K fits over one set of planes (channels_fit.hip): ONE shared resident launch for the box-constrained entry points (K <= 3, a fit
+// that fits the chip), otherwise one fit after the other.  d_x: channel c at d_x + c * x_stride; p [K][3], info [K][10], covar [K][9]: host
+int channels_fit_run(int method, int model, const double *d_angles, const double *d_x, long long x_stride, int n, int K, double *p,
+                     const double *lb, const double *ub, const double *dscl, int itmax, const double *opts, double *info, double *covar,
+                     hipStream_t stream);
+int channels_last_shared();           // 1: the last channels_fit_run on this thread was one shared launch
+FitStats channels_last_stats(int c);  // channel c of that call
+
 int capture_fit_single_run(int model, const unsigned char *d_images, int L, int H, int W, const int *d_pixel_map,
                            const double *d_vertices, const int *d_faces, const double *d_normals, int nf, const double *leds,
                            const double *view, int rv_mode, const double *p0, const double *lb, const double *ub, int itmax,

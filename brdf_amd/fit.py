@@ -65,6 +65,41 @@ def fit_single(method: int, model: int, angles, x, p0, *, lb=None, ub=None, dscl
     return FitResult(ret, p, info, None if covar is None else covar.reshape(3, 3))
 
 
+def fit_channels(method: int, model: int, angles, x, p0, *, lb=None, ub=None, dscl=None, itmax=100, opts=None, want_covar=False):
+    """K fits over ONE set of planes (brdf_hip_fit_channels_dev): the three colour channels of a capture, as the reference's
+    callers fit them (brdfdata.cpp:1159-1181).  angles: CUDA float64 [3,n]; x: CUDA float64 [K,n]; p0: [K,3] (or [3]: the same
+    start for every channel).  Returns a list of K FitResult; `last_channels_stats()` tells whether they shared one launch."""
+    import torch
+    _require(angles.is_cuda and x.is_cuda and angles.dtype == torch.float64 and x.dtype == torch.float64, "angles, x: CUDA float64 tensors")
+    angles, x = angles.contiguous(), x.contiguous()
+    _require(x.dim() == 2 and angles.numel() == 3 * x.shape[1], "angles [3,n], x [K,n]")
+    K, n = int(x.shape[0]), int(x.shape[1])
+    p = np.ascontiguousarray(np.broadcast_to(np.asarray(p0, dtype=np.float64).reshape(-1, 3), (K, 3))).copy()
+    info = np.zeros((K, 10))
+    covar = np.zeros((K, 9)) if want_covar else None
+    lba, uba, dsa = _f64(lb, 3), _f64(ub, 3), _f64(dscl, 3)
+    oa = _f64(opts, 5) if opts is not None else None
+    with torch.cuda.device(angles.device):
+        rc = lib.brdf_hip_fit_channels_dev(method, model, angles.data_ptr(), x.data_ptr(), n, n, K, _dptr(p), _dptr(lba), _dptr(uba),
+                                           _dptr(dsa), itmax, _dptr(oa), _dptr(info), _dptr(covar), _stream_handle(torch))
+    out = []
+    for c in range(K):
+        failed = info[c, 6] in (4, 7) or (rc != 0 and info[c, 6] == 0)  # levmar's LM_ERROR cases (lm_core.c:841); the ABI returns the worst channel
+        out.append(FitResult(-1 if failed else int(info[c, 5]), p[c].copy(), info[c].copy(), None if covar is None else covar[c].reshape(3, 3).copy()))
+    return out
+
+
+def last_channels_stats(channels: int = 3):
+    """per channel of the last fit_channels(): passes, jac_passes, device_us; and whether the channels shared one launch"""
+    shared = C.c_int(0)
+    per = []
+    for c in range(channels):
+        passes, jac, us = C.c_longlong(0), C.c_longlong(0), C.c_double(0.0)
+        lib.brdf_hip_last_channels_stats(c, C.byref(shared), C.byref(passes), C.byref(jac), C.byref(us))
+        per.append({"passes": passes.value, "jac_passes": jac.value, "device_us": us.value})
+    return {"shared_launch": bool(shared.value), "channels": per}
+
+
 def fit_batch(method: int, model: int, angles, x, p0, *, lb=None, ub=None, itmax=100, opts=None):
     """S independent fits.  angles: CUDA float64 [S,3,n], x: [S,n], p0: CUDA float64 [S,3] (updated in place).
 

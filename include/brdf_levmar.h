@@ -153,6 +153,22 @@ int brdf_hip_fit_dev(int method, int model, const double *d_angles, const double
                      const double *lb, const double *ub, const double *dscl, int itmax,
                      const double *opts, double *info, double *covar, void *stream);
 
+/* K fits over ONE set of planes: what the reference's callers do with the three colour channels of a capture -- one
+ * dlevmar_bc_dif call after the other over the same phi / thetaDash / theta (brdfdata.cpp:1159-1181, :1202-1219).  Channel c's
+ * measurements are d_x + c * x_stride (device); p [channels][3] in/out, info [channels][10], covar [channels][9] (or NULL): HOST.
+ * For BRDF_METHOD_BC_DIF / BRDF_METHOD_BC_DER with channels <= 3 and a fit that fits the chip the channels share ONE resident
+ * launch (the planes are read and prepared once; while one channel's sums are exchanged and its LM step runs, the others
+ * sweep): every channel's p, info and covar are bit-identical to brdf_hip_fit_dev on that channel alone.  Otherwise the
+ * channels are fitted one after the other (same results).  Returns 0, or LM_ERROR if any channel's fit failed. */
+int brdf_hip_fit_channels_dev(int method, int model, const double *d_angles, const double *d_x, long long x_stride, int n, int channels,
+                              double *p, const double *lb, const double *ub, const double *dscl, int itmax, const double *opts,
+                              double *info, double *covar, void *stream);
+/* counters of channel `channel` of the most recent brdf_hip_fit_channels_dev on this thread; *shared_launch = 1 if it was one launch */
+int brdf_hip_last_channels_stats(int channel, int *shared_launch, long long *passes, long long *jac_passes, double *device_us);
+/* diagnostic builds (-DBRDF_STAMPS) only: shader cycles per section of that channel's control wave (1 waiting for the sweeping
+ * waves, 2 reduction stage 2, 3 exchange, 4 LM step, 5 uniforms), summed over its passes */
+int brdf_hip_last_channels_stamps(int channel, long long *out8);
+
 /* S independent fits of n samples each -- the loop of CBRDFdata::CalcBRDFEquation
  * (brdfdata.cpp:1195-1220) as one call.  All array arguments are DEVICE pointers:
  *   d_angles[S][3][n], d_x[S][n], d_p[S][3] (in: starting points, out: fitted), d_info[S][10] (or NULL),

@@ -289,6 +289,52 @@ def test_shared_sweeps_do_not_change_a_bit(gpu, monkeypatch, model, n):
     assert fewer > 0
 
 
+def _channel_measurements(model, angles, n):
+    """three measurement vectors over ONE set of planes: the model at three truths + seeded noise (the three colour channels
+    of a capture share phi / thetaDash / theta, brdfdata.cpp:1159-1181)"""
+    rng = np.random.default_rng(20240 + model)
+    truths = {2: ((0.35, 0.25, 0.15), (0.6, 0.1, 0.3), (0.2, 0.4, 0.08)), 1: ((0.35, 0.6, 24.0), (0.5, 0.3, 8.0), (0.2, 0.8, 40.0)),
+              0: ((0.35, 0.06, 24.0), (0.5, 0.03, 8.0), (0.2, 0.08, 40.0))}[model]
+    return np.stack([L.model_values(model, angles, t) + 0.01 * (rng.random(n) - 0.5) for t in truths])
+
+
+@pytest.mark.parametrize("model,n", [(2, 1_000_000), (1, 402_928), (2, 262_145), (0, 100_003), (1, 5_000), (2, 300)])
+def test_channels_sharing_a_launch_equal_single_fits_bit_for_bit(gpu, model, n):
+    """brdf_hip_fit_channels_dev: three dlevmar_bc_dif (and dlevmar_bc_der) fits over one set of planes in ONE resident
+    launch -- three control waves, four sweeping waves serving whichever channel has a request out.  Every channel's p,
+    info[] and covariance must equal the single-fit resident path's on that channel alone, bit for bit (same sample ->
+    lane -> slot mapping, same accumulation order, same trees; only who executes an operation differs); sizes from a
+    one-workgroup fit to the full chip, one with a short last workgroup, and the bunny's 402,928 samples."""
+    torch, brdf_amd, dev = gpu
+    angles, _, _ = synth.make_single(model, n)
+    xs = _channel_measurements(model, angles, n)
+    a = torch.from_numpy(np.ascontiguousarray(angles)).to(dev)
+    xd = torch.from_numpy(np.ascontiguousarray(xs)).to(dev)
+    for method in (1, 2):
+        lb, ub = synth.bounds(model) if method == 2 else (synth.LB, synth.UB)
+        kw = dict(lb=lb, ub=ub, itmax=synth.ITMAX, opts=synth.OPTS, want_covar=True)
+        for K in (3, 2):
+            together = brdf_amd.fit_channels(method, model, a, xd[:K], synth.P0[model], **kw)
+            st = brdf_amd.last_channels_stats(K)
+            assert st["shared_launch"], st
+            for c in range(K):
+                alone = brdf_amd.fit_single(method, model, a, xd[c], synth.P0[model], **kw)
+                assert brdf_amd.last_fit_stats()["launches"] == 1
+                what = (method, K, c, together[c], alone)
+                assert together[c].ret == alone.ret and np.array_equal(together[c].p, alone.p), what
+                assert np.array_equal(together[c].info, alone.info), what
+                assert np.array_equal(together[c].covar, alone.covar), what
+                assert st["channels"][c]["passes"] == brdf_amd.last_fit_stats()["passes"]
+    # the entry points that keep per-sample state per channel, and more channels than the shared launch takes, run one fit
+    # after the other through the same call: same results
+    for method, K in ((0, 3), (3, 2)):
+        res = brdf_amd.fit_channels(method, model, a, xd[:K], synth.P0[model], itmax=synth.ITMAX, opts=synth.OPTS)
+        assert not brdf_amd.last_channels_stats(K)["shared_launch"]
+        for c in range(K):
+            alone = brdf_amd.fit_single(method, model, a, xd[c], synth.P0[model], itmax=synth.ITMAX, opts=synth.OPTS)
+            assert np.array_equal(res[c].p, alone.p) and np.array_equal(res[c].info, alone.info)
+
+
 # ---- batched regime ------------------------------------------------------------------------------------
 def _batch(gpu, method, model, angles, x, p0):
     torch, brdf_amd, dev = gpu
