@@ -162,14 +162,32 @@ __global__ __launch_bounds__(THREADS, (batch_waves_per_simd<THREADS, SPT>())) vo
     case RQ_EVAL_MULTI:
       if constexpr (METHOD == 1 && THREADS < 512) {  // the 512 x 8 geometry never asks for it (see batch_fit_enqueue): keeping the
                                        // unrolled 8 x 8 body out of that kernel keeps its samples in registers
+        if (u.ncand == kMaxCand) {  // the usual case: no guard between a sample's candidates, four independent exp chains per basic
+                                    // block (resident_fit_impl.h, RQ_EVAL_MULTI: a guarded candidate's chain runs alone)
 #pragma unroll
-        for (int k = 0; k < SPT; ++k) {
+          for (int k = 0; k < SPT; ++k) {
 #pragma unroll
-          for (int j = 0; j < kMaxCand; ++j)
-            if (j < u.ncand) {
-              const double e = ok[k] ? sx[k] - model_value_k<MODEL, FAST>(u, j, s0[k], pq[k]) : 0.0;
-              acc[j] += e * e;
+            for (int j0 = 0; j0 < kMaxCand; j0 += 4) {
+              double e[4];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) e[j] = sx[k] - model_value_k<MODEL, FAST>(u, j0 + j, s0[k], pq[k]);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                if (!ok[k]) e[j] = 0.0;
+                acc[j0 + j] += e[j] * e[j];
+              }
             }
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < SPT; ++k) {
+#pragma unroll
+            for (int j = 0; j < kMaxCand; ++j)
+              if (j < u.ncand) {
+                const double e = ok[k] ? sx[k] - model_value_k<MODEL, FAST>(u, j, s0[k], pq[k]) : 0.0;
+                acc[j] += e * e;
+              }
+          }
         }
         block_reduce<kMaxCand, THREADS>(acc, mx, red, sums);
       }
@@ -187,18 +205,31 @@ __global__ __launch_bounds__(THREADS, (batch_waves_per_simd<THREADS, SPT>())) vo
       break;
     case RQ_JAC:
       if constexpr (METHOD != 0) {
+      // (the row's kind -- analytic, central or forward differences -- is the same for every sample: chosen outside the sample
+      // loop, whose bodies then are straight-line code in which the exp chains interleave; see resident_fit_impl.h, RQ_JAC)
+      auto jac_rows = [&](auto jk) {
+        constexpr int JK = decltype(jk)::value;
 #pragma unroll
-      for (int k = 0; k < SPT; ++k) {
-        double f0 = 0.0, j[kM];
-        if (METHOD == 2 || u.analytic)  // dlevmar_der / dlevmar_bc_der: the model's analytic Jacobian
-          model_an_row<MODEL, FAST>(u, s0[k], pq[k], f0, j);
-        else
-          model_fd_row<MODEL, FAST>(u, s0[k], pq[k], true, f0, 0.0, false, j);
-        double e = sx[k] - f0;
-        if (!ok[k]) e = j[0] = j[1] = j[2] = 0.0;
-        acc_normal_eq(j, e, acc, acc + kNL);
-        acc[kNL + kM] += e * e;
-      }
+        for (int k = 0; k < SPT; ++k) {
+          double f0 = 0.0, j[kM];
+          if (JK == 2)  // dlevmar_der / dlevmar_bc_der: the model's analytic Jacobian
+            model_an_row<MODEL, FAST>(u, s0[k], pq[k], f0, j);
+          else if (JK == 1)
+            model_fd_row_t<MODEL, FAST, true>(u, s0[k], pq[k], true, f0, 0.0, false, j);
+          else
+            model_fd_row_t<MODEL, FAST, false>(u, s0[k], pq[k], true, f0, 0.0, false, j);
+          double e = sx[k] - f0;
+          if (!ok[k]) e = j[0] = j[1] = j[2] = 0.0;
+          acc_normal_eq(j, e, acc, acc + kNL);
+          acc[kNL + kM] += e * e;
+        }
+      };
+      if (METHOD == 2 || u.analytic)
+        jac_rows(std::integral_constant<int, 2>{});
+      else if (u.central)
+        jac_rows(std::integral_constant<int, 1>{});
+      else
+        jac_rows(std::integral_constant<int, 0>{});
       block_reduce<SumLayout<kM>::JAC, THREADS>(acc, mx, red, sums);
       }
       break;

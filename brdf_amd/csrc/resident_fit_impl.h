@@ -202,6 +202,10 @@ __device__ __forceinline__ void for_sample_pairs(int nk, F &&f) {
   }
 }
 
+__device__ __forceinline__ constexpr bool pend_flag(std::true_type) { return true; }
+__device__ __forceinline__ constexpr bool pend_flag(std::false_type) { return false; }
+__device__ __forceinline__ constexpr bool pend_flag(bool b) { return b; }
+
 // Reduction of NS sums and one max over the eight waves: two DPP steps inside each row of 16 lanes leave the sum of
 // every 4 consecutive lanes in lanes 3,7,11,..; those park their values as buf[slot][thread/4]; wave w then owns slots
 // {w, w+8}: each lane adds its two entries and one DPP tree per slot finishes it.  A pure function of NS: reproducible.
@@ -468,6 +472,30 @@ __device__ __forceinline__ void sweep_pass(int kind, const PassUniforms<MODEL> &
     break;
   case RQ_EVAL_MULTI:  // bc: candidates of a projected-gradient search; dif: the trial points of a chain of rejections
     if constexpr (METHOD != 2) {
+#ifndef BRDF_EXP_MULTI_GUARDED
+      if (u.ncand == kMaxCand) {
+        // the usual case, a full set of candidates: no `j < ncand` guard between the candidates of a sample, so that four
+        // independent exp chains share a basic block and interleave (guarded, every candidate is a block of its own and its
+        // chain runs alone: scripts/micro/exp_ilp.hip measures 76 cycles per exp and SIMD that way, 51 with four side by side)
+        for_samples<U>(nk, [&](int k) {
+          const double c0 = st.get(kFc0, k), x = st.get(kFx, k);
+          const Prep q = prep(k);
+          const bool d = dead(k);
+#pragma unroll
+          for (int j0 = 0; j0 < kMaxCand; j0 += 4) {
+            double e[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e[j] = x - model_value_k<MODEL, FAST>(u, j0 + j, c0, q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              if (d) e[j] = 0.0;
+              acc[j0 + j] = fma(e[j], e[j], acc[j0 + j]);
+            }
+          }
+        });
+        break;
+      }
+#endif
       for_samples<U>(nk, [&](int k) {
         const double c0 = st.get(kFc0, k), x = st.get(kFx, k);
         const Prep q = prep(k);
@@ -503,12 +531,26 @@ __device__ __forceinline__ void sweep_pass(int kind, const PassUniforms<MODEL> &
           acc[kNL + kM] = fma(e, e, acc[kNL + kM]);
         });
       };
+#ifdef BRDF_EXP_OLD_JAC
+      for_bc([&](int k) {
+        double f0 = 0.0, j[kM];
+        if (u.analytic)
+          model_an_row<MODEL, FAST>(u, st.get(kFc0, k), prep(k), f0, j);
+        else
+          model_fd_row<MODEL, FAST>(u, st.get(kFc0, k), prep(k), true, f0, 0.0, false, j);
+        double e = st.get(kFx, k) - f0;
+        if (dead(k)) e = j[0] = j[1] = j[2] = 0.0;
+        acc_normal_eq_fma(j, e, acc, acc + kNL);
+        acc[kNL + kM] = fma(e, e, acc[kNL + kM]);
+      });
+#else
       if (u.analytic)
         jac(std::integral_constant<int, 2>{});
       else if (u.central)
         jac(std::integral_constant<int, 1>{});
       else
         jac(std::integral_constant<int, 0>{});
+#endif
     }
     break;
   case RQ_DIF_INIT:
@@ -542,11 +584,11 @@ __device__ __forceinline__ void sweep_pass(int kind, const PassUniforms<MODEL> &
     if constexpr (METHOD == 0) {
       const double rinv = 1.0 / u.dp_l2;
       auto value_q = [&](int k) { return model_value_q<MODEL, FAST>(u, st.get(kFc0, k), prep(k)); };
-      auto body = [&](int k, const double w) {
+      auto body = [&](auto pend_c, int k, const double w) {
         const int s = k * kRThreads + tid;
         const double h = st.get(kFhx, k), x = st.get(kFx, k);
         double jo[kM] = {jl[s], jl[kRCap + s], jl[2 * kRCap + s]};
-        if (pend) {  // adopt the previous trial's update: the same operation that formed its jn[] below
+        if (pend_flag(pend_c)) {  // adopt the previous trial's update: the same operation that formed its jn[] below
           const double tp = st.get(kFtb, k);
 #pragma unroll
           for (int j = 0; j < kM; ++j) jo[j] = fma(tp, dpp[j], jo[j]);
@@ -583,7 +625,16 @@ __device__ __forceinline__ void sweep_pass(int kind, const PassUniforms<MODEL> &
       };
       // (the exp chains of two samples side by side and the Broyden / accumulation halves one after the other was measured too:
       // 455 against 446 us per 10^6-sample fit; whole bodies in pairs spill 28-36 VGPRs)
-      for_samples<U>(nk, [&](int k) { body(k, value_q(k)); });
+#ifdef BRDF_TRIAL_HOIST_PEND
+      // (whether the previous trial's update is pending is the same for every sample: chosen outside the body, which then is one
+      // basic block in which the exp chain, the LDS reads of the row and the Broyden arithmetic can interleave)
+      if (pend)
+        for_samples<U>(nk, [&](int k) { body(std::true_type{}, k, value_q(k)); });
+      else
+        for_samples<U>(nk, [&](int k) { body(std::false_type{}, k, value_q(k)); });
+#else
+      for_samples<U>(nk, [&](int k) { body(pend, k, value_q(k)); });  // (the branch stays in the body)
+#endif
     }
     break;
   default: break;  // unknown request: the control wave will not survive it either
@@ -605,8 +656,13 @@ __device__ __forceinline__ void reduce_pass(int kind, const double *acc, double 
     switch (kind) {
     // (max |e| is read after plain evaluations only -- the overflow guards of lmbc_core.c:748, :915 -- so the Jacobian and
     // multi-candidate passes carry no max slot: one reduction value, one exchange cell and one gather instruction less)
+#ifdef BRDF_EXP_KEEP_MAX
+    case RQ_JAC: worker_reduce<SumLayout<kM>::JAC, true>(acc, mx, red, sums, st_, last_); break;
+    case RQ_EVAL_MULTI: worker_reduce<kMaxCand, true>(acc, mx, red, sums, st_, last_); break;
+#else
     case RQ_JAC: worker_reduce<SumLayout<kM>::JAC, false>(acc, mx, red, sums, st_, last_); break;
     case RQ_EVAL_MULTI: worker_reduce<kMaxCand, false>(acc, mx, red, sums, st_, last_); break;
+#endif
     default: worker_reduce<1, METHOD == 1>(acc, mx, red, sums, st_, last_); break;  // (dlevmar_der never reads max |e|)
     }
   }
@@ -682,7 +738,7 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
     if constexpr (METHOD == 0) {
       sm.start(p0, n, itmax, po, want_covar, /*speculative=*/1, chain);
     } else if constexpr (METHOD == 1) {
-      sm.start(p0, n, has_lb ? lb : nullptr, has_ub ? ub : nullptr, has_dscl ? dscl : nullptr, itmax, po, want_covar, multi, spec_jac);
+      sm.start(p0, n, has_lb ? lb : nullptr, has_ub ? ub : nullptr, has_dscl ? dscl : nullptr, itmax, po, want_covar, multi, BATCHED ? 0 : spec_jac);
       sm.c.analytic_jac = analytic;
     } else {
       sm.start(p0, n, itmax, po, want_covar);
@@ -865,7 +921,7 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
         if constexpr (METHOD == 0)
           sm.template step<true, true>(sums, sums[kSums]);  // (+ chains of rejections, several trial points to a sweep)
         else if constexpr (METHOD == 1)
-          sm.template step<true, true, false, true>(sums, sums[kSums]);  // (+ candidates evaluated by Jacobian passes)
+          sm.template step<true, true, false, !BATCHED>(sums, sums[kSums]);  // (+ candidates evaluated by Jacobian passes: single fits only)
         else
           sm.template step<true>(sums, sums[kSums]);
       }
