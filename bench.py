@@ -631,6 +631,67 @@ def single_line(args, model, ctx, steps, warmup, angles, x, rank0_cpu):
     return line, rc
 
 
+def channels_line(args, model, ctx, steps, warmup, angles, x, K=3):
+    """K colour channels over ONE set of planes (the reference's callers: brdfdata.cpp:1159-1181): one truth, K noise draws;
+    dlevmar_bc_dif through brdf_hip_fit_channels_dev (ONE shared resident launch) against K single-fit launches one after the
+    other.  Rank 0's line."""
+    from brdf_amd import synth
+    torch, dist, rank, world, backend, dev, stub = ctx
+    import brdf_amd
+    lb, ub, itmax, opts, p0 = synth.LB, synth.UB, synth.ITMAX, synth.OPTS, synth.P0[model]
+    a_dev = torch.from_numpy(angles).to(dev)
+    clean = brdf_amd.model_eval(model, a_dev, synth.TRUTH[model])  # (the product's K1 kernel: f(truth) on the planes)
+    gen = torch.Generator(device="cpu").manual_seed(20240 + model)
+    xs = [torch.from_numpy(x).to(dev)] + [clean + (0.01 * (torch.rand(x.size, generator=gen, dtype=torch.float64) - 0.5)).to(dev) for _ in range(K - 1)]
+    xd = torch.stack(xs).contiguous()
+    kw = dict(lb=lb, ub=ub, itmax=itmax, opts=opts)
+
+    def timed(fn):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        t0 = time.perf_counter()
+        for s_ in range(steps):
+            evs[s_][0].record()
+            r = fn()
+            evs[s_][1].record()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        return r, wall, sum(a.elapsed_time(b) for a, b in evs) * 1e3 / steps
+
+    shared, wall_sh, us_sh = timed(lambda: brdf_amd.fit_channels(1, model, a_dev, xd, p0, **kw))
+    st = brdf_amd.last_channels_stats(K)
+    serial, wall_se, us_se = timed(lambda: [brdf_amd.fit_single(1, model, a_dev, xd[c], p0, **kw) for c in range(K)])
+    nfev = [float(r.info[7]) for r in shared]
+    njev = [float(r.info[8]) for r in shared]
+    ref_passes = sum(nj + (nf - 4.0 * nj) for nf, nj in zip(nfev, njev))  # the reference's streaming visits, all channels
+    evals = sum(nfev) * N_SAMPLES
+    bpsp = BYTES_PER_SAMPLE_PASS[model]
+    planes_b = bpsp - 8  # the planes' share of a sample-pass; 8 B = the measurement
+    per_fit = bpsp * N_SAMPLES * ref_passes / (us_sh * 1e-6) / 1e9               # every channel pass reads planes + its measurement
+    shared_planes = (planes_b + 8 * K) / K * N_SAMPLES * ref_passes / (us_sh * 1e-6) / 1e9  # a round of K passes reads the planes once
+    identical = all(np.array_equal(a.p, b.p) and np.array_equal(a.info, b.info) for a, b in zip(shared, serial))
+    kernel = f"channels_fit_kernel<{model}, true>"
+    traffic, traffic_src = profiled_traffic(kernel)
+    return {
+        "workload": f"{K} channels over one set of planes (one truth, {K} noise draws), {MODEL_NAME[model]}, 1,000,000 samples each, dlevmar_bc_dif, "
+                    "brdf_hip_fit_channels_dev: one shared resident launch; one step = the K fits",
+        "channels": K, "entry_point": "dlevmar_bc_dif", "steps": steps, "shared_launch": bool(st["shared_launch"]),
+        "value": evals * steps / wall_sh, "unit": "residual-evals/s", "ms_per_step": 1e3 * wall_sh / steps, "launch_us": us_sh,
+        "one_after_the_other": {"ms_per_step": 1e3 * wall_se / steps, "launches_us": us_se, "speedup_of_the_shared_launch": us_se / us_sh},
+        "nfev": nfev, "passes": [c["passes"] for c in st["channels"]], "bit_identical_to_single_fits": bool(identical),
+        "fitted_params": [[float(v) for v in r.p] for r in shared],
+        "roofline": {"bound": "hbm", "kernel": "brdf::" + kernel, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "achieved": per_fit, "frac": per_fit / HBM_PEAK_GBS,
+                     "achieved_shared_planes": shared_planes, "frac_shared_planes": shared_planes / HBM_PEAK_GBS,
+                     "reference_passes_per_launch": ref_passes, "traffic": traffic, "traffic_source": traffic_src,
+                     "alu": alu_roofline(kernel, evals / (us_sh * 1e-6), evals),
+                     "note": f"achieved: SURVEY.md section 8d's {bpsp} B per sample-pass per fit x the passes of the reference algorithm over all {K} "
+                             f"channels / the launch; achieved_shared_planes: ({planes_b} + 8 K) / K B per sample-pass per fit -- the {K} channels' "
+                             "passes of one round share one read of the planes"}}
+
+
 def main_single(args, model):
     """c2 / c3.  The default run (`python bench.py`: c2 on one GPU) also carries the other BASELINE.json configurations as
     short sub-lines under `configs`: c3 through both entry points, c4 and c5 through dlevmar_dif -- a few steps each, parity
@@ -653,6 +714,8 @@ def main_single(args, model):
     ctx = dist_setup(args)
     torch, dist, rank, world = ctx[0], ctx[1], ctx[2], ctx[3]
     line, rc = single_line(args, model, ctx, args.steps, args.warmup, angles, x, rank0_cpu)
+    if rank == 0 and args.channels > 1 and os.environ.get("BRDF_BENCH_STUB") != "1":
+        line["channels"] = channels_line(args, model, ctx, args.steps, args.warmup, angles, x, args.channels)
     if rank == 0 and subs:
         configs = {}
         try:
@@ -663,6 +726,11 @@ def main_single(args, model):
             for part in (configs["c3"], configs["c3"].get("bc_dif", {})):
                 part.pop("cpu_baseline", None)  # (one untimed CPU fit per entry point: a parity reference, not a baseline)
             rc = rc or rc3
+            if args.channels <= 1:
+                configs["c2_three_channels"] = channels_line(args, model, ctx, 10, 2, angles, x, 3)
+                if not configs["c2_three_channels"]["bit_identical_to_single_fits"]:
+                    print("bench.py: the shared launch's channels differ from single fits", file=sys.stderr)
+                    rc = rc or 3
             for wl in ("c4", "c5"):
                 lb_ = batched_line(args, wl, "dif", ctx, 2, 1, None, sub_cpu[wl])
                 configs[wl + "_dif"] = {k: lb_[k] for k in ("value", "ms_per_step", "steps", "config", "roofline", "result_sha256", "parity",
@@ -692,6 +760,8 @@ def main():
                          "c4 / c5: configs[3] / [4], the multi-surfel configurations, surfels sharded over the ranks (strong scaling)")
     ap.add_argument("--entry", default="dif", choices=["dif", "bc_dif"], help="entry point for c4 / c5")
     ap.add_argument("--headline-only", action="store_true", help="c2 on one GPU without the configs[2..4] sub-lines")
+    ap.add_argument("--channels", type=int, default=1, help="c2 / c3: add a line for K colour channels over one set of planes (dlevmar_bc_dif, "
+                    "brdf_hip_fit_channels_dev: one shared resident launch) next to the headline")
     ap.add_argument("--surfels", type=int, default=0, help=argparse.SUPPRESS)  # rehearsal / tests: shrink c4 / c5
     ap.add_argument("--samples", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()

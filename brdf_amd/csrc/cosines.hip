@@ -16,6 +16,7 @@
 // HBM-bound: per surfel 4 B (index) + 12 B (face) + 72 B (3 vertices, gathered) + 24 B (normal) in, 3 * L * 8 B out
 // (L = 16: 384 B), i.e. 496 B of algorithmic traffic per surfel.
 #include <cstdio>
+#include <cstdlib>
 
 #include "stream_fit.h"
 
@@ -64,6 +65,95 @@ __device__ __forceinline__ void normalize3(double *v) {  // Eigen: if (squaredNo
   }
 }
 
+// what a lane computes once it holds its surfel's centre c, normal nrm and its light l: the three cosines
+__device__ __forceinline__ void cosines_of(const CosArgs &a, const double *c, const double *nrm, const double *l, double &cos_ln, double &cos_nh,
+                                           double &cos_rv) {
+  // cos(L.N), brdfdata.cpp:886-895
+  double ld[3] = {l[0] - c[0], l[1] - c[1], l[2] - c[2]};
+  normalize3(ld);
+  cos_ln = dot3(ld, nrm);
+
+  // cos(N.H), brdfdata.cpp:930-939: H = (led - c) + (view - c), written as led - 2*c + view
+  double h[3] = {l[0] - 2 * c[0] + a.view[0], l[1] - 2 * c[1] + a.view[1], l[2] - 2 * c[2] + a.view[2]};
+  normalize3(h);
+  cos_nh = dot3(h, nrm);
+
+  // cos(R.V), brdfdata.cpp:828-853
+  if (a.rv_mode == 0) {
+    double md[3] = {c[0] - l[0], c[0] - l[1], c[0] - l[2]};  // (sic) "x - m_led(i,1)", "x - m_led(i,2)"
+    normalize3(md);
+    const double sf = dot3(nrm, md);
+    const double P[3] = {sf * nrm[0], sf * nrm[1], sf * nrm[2]};
+    const double R[3] = {md[0] - 2 * P[0], md[1] - 2 * P[1], md[2] - 2 * P[2]};
+    cos_rv = dot3(R, P);  // (sic) R.P
+  } else {
+    double vd[3] = {a.view[0] - c[0], a.view[1] - c[1], a.view[2] - c[2]};
+    normalize3(vd);
+    double md[3] = {c[0] - l[0], c[1] - l[1], c[2] - l[2]};  // -1 * light vector
+    normalize3(md);
+    const double sf = dot3(nrm, md);
+    const double P[3] = {sf * nrm[0], sf * nrm[1], sf * nrm[2]};
+    const double R[3] = {md[0] - 2 * P[0], md[1] - 2 * P[1], md[2] - 2 * P[2]};
+    cos_rv = dot3(R, vd);
+  }
+}
+
+// lane N's value in all 16 lanes of its DPP row (row_newbcast:N)
+template <int N>
+__device__ __forceinline__ int row_bcast_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, 0x150 + N, 0xf, 0xf, false);
+}
+template <int N>
+__device__ __forceinline__ double row_bcast_d(double v) {
+  return __hiloint2double(row_bcast_i<N>(__double2hiint(v)), row_bcast_i<N>(__double2loint(v)));
+}
+
+// L = 16 (the capture rig, brdfdata.h:58): a DPP row of 16 lanes is one surfel's 16 lights.  The surfel's 112 bytes -- index, three
+// vertex indices, nine vertex coordinates, three normal components -- are loaded ONCE per row (lane j < 3 a vertex index, then lane
+// j < 9 a coordinate and lanes 9..11 the normal) and handed round by row broadcasts, instead of once per lane (sixteen lanes each
+// chasing surfel -> face -> vertices: 16 load instructions per lane, three deep).  Same arithmetic per lane afterwards: same bits.
+__global__ __launch_bounds__(256) void cosines_rows_kernel(CosArgs a) {
+  __shared__ double led[16][3];
+  if (threadIdx.x < 48) led[threadIdx.x / 3][threadIdx.x % 3] = a.leds[threadIdx.x / 3][threadIdx.x % 3];
+  __syncthreads();
+  const int i = (int)threadIdx.x & 15, local = (int)threadIdx.x >> 4;
+  const double l[3] = {led[i][0], led[i][1], led[i][2]};
+  for (long long s0 = (long long)blockIdx.x * 16; s0 < a.S; s0 += (long long)gridDim.x * 16) {
+    const long long s = s0 + local;
+    const bool live = s < a.S;  // (whole rows: every lane of a row agrees)
+    const long long ss = live ? s : a.S - 1;
+    const int f = a.surfels ? a.surfels[ss] : (int)ss;
+    const int vmine = a.faces[3 * (size_t)f + (i < 3 ? i : 0)];  // lanes 0..2: the face's vertex indices
+    const int v0 = row_bcast_i<0>(vmine), v1 = row_bcast_i<1>(vmine), v2 = row_bcast_i<2>(vmine);
+    const int vsel = i < 3 ? v0 : (i < 6 ? v1 : v2);
+    const int comp = i < 9 ? i % 3 : 0;
+    const double *src = (i < 9) ? a.vertices + 3 * (size_t)vsel + comp : a.normals + 3 * (size_t)f + (i < 12 ? i - 9 : 0);
+    const double mine = *src;  // lanes 0..8: vertex coordinates (v0.xyz, v1.xyz, v2.xyz); 9..11: the normal
+    const double x0[3] = {row_bcast_d<0>(mine), row_bcast_d<1>(mine), row_bcast_d<2>(mine)};
+    const double x1[3] = {row_bcast_d<3>(mine), row_bcast_d<4>(mine), row_bcast_d<5>(mine)};
+    const double x2[3] = {row_bcast_d<6>(mine), row_bcast_d<7>(mine), row_bcast_d<8>(mine)};
+    const double nrm[3] = {row_bcast_d<9>(mine), row_bcast_d<10>(mine), row_bcast_d<11>(mine)};
+    double c[3];  // centre of the triangle: x = 0; x += each vertex; x /= 3.0   (brdfdata.cpp:816-827)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      double t = 0.0;
+      t += x0[k];
+      t += x1[k];
+      t += x2[k];
+      const double at = fabs(t);
+      c[k] = (at > 1e-290 && at < 1e300) ? div_by_r(t, 3.0, 1.0 / 3.0) : t / 3.0;  // (t == 0 takes the division)
+    }
+    double cos_ln, cos_nh, cos_rv;
+    cosines_of(a, c, nrm, l, cos_ln, cos_nh, cos_rv);
+    if (live) {
+      double *out = a.angles + (size_t)s * 48 + i;
+      out[0] = cos_ln;
+      out[16] = cos_nh;
+      out[32] = cos_rv;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void cosines_kernel(CosArgs a) {
   __shared__ double led[kMaxLights][3];
   for (int t = threadIdx.x; t < 3 * a.L; t += blockDim.x) led[t / 3][t % 3] = a.leds[t / 3][t % 3];
@@ -90,35 +180,8 @@ __global__ __launch_bounds__(256) void cosines_kernel(CosArgs a) {
     const double nrm[3] = {a.normals[3 * (size_t)f], a.normals[3 * (size_t)f + 1], a.normals[3 * (size_t)f + 2]};
     const double l[3] = {led[i][0], led[i][1], led[i][2]};
 
-    // cos(L.N), brdfdata.cpp:886-895
-    double ld[3] = {l[0] - c[0], l[1] - c[1], l[2] - c[2]};
-    normalize3(ld);
-    const double cos_ln = dot3(ld, nrm);
-
-    // cos(N.H), brdfdata.cpp:930-939: H = (led - c) + (view - c), written as led - 2*c + view
-    double h[3] = {l[0] - 2 * c[0] + a.view[0], l[1] - 2 * c[1] + a.view[1], l[2] - 2 * c[2] + a.view[2]};
-    normalize3(h);
-    const double cos_nh = dot3(h, nrm);
-
-    // cos(R.V), brdfdata.cpp:828-853
-    double cos_rv;
-    if (a.rv_mode == 0) {
-      double md[3] = {c[0] - l[0], c[0] - l[1], c[0] - l[2]};  // (sic) "x - m_led(i,1)", "x - m_led(i,2)"
-      normalize3(md);
-      const double sf = dot3(nrm, md);
-      const double P[3] = {sf * nrm[0], sf * nrm[1], sf * nrm[2]};
-      const double R[3] = {md[0] - 2 * P[0], md[1] - 2 * P[1], md[2] - 2 * P[2]};
-      cos_rv = dot3(R, P);  // (sic) R.P
-    } else {
-      double vd[3] = {a.view[0] - c[0], a.view[1] - c[1], a.view[2] - c[2]};
-      normalize3(vd);
-      double md[3] = {c[0] - l[0], c[1] - l[1], c[2] - l[2]};  // -1 * light vector
-      normalize3(md);
-      const double sf = dot3(nrm, md);
-      const double P[3] = {sf * nrm[0], sf * nrm[1], sf * nrm[2]};
-      const double R[3] = {md[0] - 2 * P[0], md[1] - 2 * P[1], md[2] - 2 * P[2]};
-      cos_rv = dot3(R, vd);
-    }
+    double cos_ln, cos_nh, cos_rv;
+    cosines_of(a, c, nrm, l, cos_ln, cos_nh, cos_rv);
     double *out = a.angles + (size_t)s * 3 * a.L + i;
     out[0] = cos_ln;
     out[a.L] = cos_nh;
@@ -150,7 +213,11 @@ int cosines_run(const double *d_vertices, const int *d_faces, const double *d_no
   const long long per_block = 256 / L;  // whole surfels per workgroup and trip
   long long blocks = (S + per_block - 1) / per_block;
   if (blocks > 256 * 64) blocks = 256 * 64;  // grid-stride beyond 64 workgroups per CU
-  hipLaunchKernelGGL(cosines_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+  static const bool rows_off = [] { const char *e = getenv("BRDF_HIP_COSINES_ROWS"); return e && e[0] == '0'; }();
+  if (L == 16 && !rows_off)
+    hipLaunchKernelGGL(cosines_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+  else
+    hipLaunchKernelGGL(cosines_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     set_error("cosines_kernel launch failed: %s", hipGetErrorString(e));

@@ -25,7 +25,7 @@
 
 namespace brdf {
 
-constexpr int kGenMaxM = 8;
+constexpr int kGenMaxM = 16;  // (levmar takes any m, lm_core.c:528-548; the machines are instantiated per m: 1..16 here)
 constexpr int kGenSums = kGenMaxM * (kGenMaxM + 1) / 2 + kGenMaxM + 2;  // JtJ lower + Jte + ||e||^2 + max
 constexpr int kGenThreads = 256;
 constexpr int kGenExactLimit = 65536;
@@ -419,6 +419,14 @@ int generic_dispatch(user_func_of<Real> func, user_jacf_of<Real> jacf, Real *p, 
   case 6: return generic_run<6, METHOD, Real>(func, jacf, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
   case 7: return generic_run<7, METHOD, Real>(func, jacf, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
   case 8: return generic_run<8, METHOD, Real>(func, jacf, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
+  case 9: return generic_run<9, METHOD, Real>(func, jacf, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
+  case 10: return generic_run<10, METHOD, Real>(func, jacf, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
+  case 11: return generic_run<11, METHOD, Real>(func, jacf, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
+  case 12: return generic_run<12, METHOD, Real>(func, jacf, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
+  case 13: return generic_run<13, METHOD, Real>(func, jacf, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
+  case 14: return generic_run<14, METHOD, Real>(func, jacf, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
+  case 15: return generic_run<15, METHOD, Real>(func, jacf, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
+  case 16: return generic_run<16, METHOD, Real>(func, jacf, p, x, n, lb, ub, dscl, itmax, opts, info, covar, adata);
   }
   set_error("generic callback path supports 1 <= m <= %d parameters (got %d)", kGenMaxM, m);
   return kLmError;

@@ -155,21 +155,23 @@ LM_HD bool lm_finite(Real v) { return (v - v) == Real(0.0); }  // false for NaN 
 
 // Crout LU with implicit row scaling + partial pivoting and the DBL_EPSILON zero-pivot rule, then
 // forward/back substitution: Axb_core.c:1197-1270.  A, B untouched; returns 0 if a row of A is zero.
+// (M <= 8: fully unrolled; the wide instantiations of the host-callback path, M = 9..16, run on the host and keep their loops.)
 // Every array index below is a compile-time constant after unrolling (row exchanges and the
 // permuted right-hand-side picks are written as selects over all candidate rows), so on the GPU the
 // factorisation lives entirely in registers -- no scratch memory, no indirect register access.
 template <int M, class Real>
 LM_HD int lu_solve(const Real *A, const Real *B, Real *x) {
+  constexpr int kUnrollLu = M <= 8 ? 64 : 1;  // (unroll count of every loop below: all of it, or nothing)
   Real a[M * M], scale[M];
   int perm[M];
-#pragma unroll
+#pragma unroll kUnrollLu
   for (int i = 0; i < M * M; ++i) a[i] = A[i];
-#pragma unroll
+#pragma unroll kUnrollLu
   for (int i = 0; i < M; ++i) x[i] = B[i];
-#pragma unroll
+#pragma unroll kUnrollLu
   for (int i = 0; i < M; ++i) {
     Real big = Real(0.0);
-#pragma unroll
+#pragma unroll kUnrollLu
     for (int j = 0; j < M; ++j) {
       const Real t = lm_abs(a[i * M + j]);
       if (t > big) big = t;
@@ -177,21 +179,21 @@ LM_HD int lu_solve(const Real *A, const Real *B, Real *x) {
     if (big == Real(0.0)) return 0;
     scale[i] = Real(1.0) / big;
   }
-#pragma unroll
+#pragma unroll kUnrollLu
   for (int j = 0; j < M; ++j) {
     int pivot = j;
     Real big = Real(0.0);
-#pragma unroll
+#pragma unroll kUnrollLu
     for (int i = 0; i < j; ++i) {
       Real s = a[i * M + j];
-#pragma unroll
+#pragma unroll kUnrollLu
       for (int k = 0; k < i; ++k) s -= a[i * M + k] * a[k * M + j];
       a[i * M + j] = s;
     }
-#pragma unroll
+#pragma unroll kUnrollLu
     for (int i = j; i < M; ++i) {
       Real s = a[i * M + j];
-#pragma unroll
+#pragma unroll kUnrollLu
       for (int k = 0; k < j; ++k) s -= a[i * M + k] * a[k * M + j];
       a[i * M + j] = s;
       const Real t = scale[i] * lm_abs(s);
@@ -201,10 +203,10 @@ LM_HD int lu_solve(const Real *A, const Real *B, Real *x) {
       }
     }
     // exchange rows j and pivot (pivot >= j); scale[pivot] <- scale[j]
-#pragma unroll
+#pragma unroll kUnrollLu
     for (int r = j + 1; r < M; ++r) {
       if (pivot == r) {
-#pragma unroll
+#pragma unroll kUnrollLu
         for (int k = 0; k < M; ++k) {
           const Real t = a[r * M + k];
           a[r * M + k] = a[j * M + k];
@@ -217,16 +219,16 @@ LM_HD int lu_solve(const Real *A, const Real *B, Real *x) {
     if (a[j * M + j] == Real(0.0)) a[j * M + j] = LmLimits<Real>::eps();
     if (j != M - 1) {
       const Real t = Real(1.0) / a[j * M + j];
-#pragma unroll
+#pragma unroll kUnrollLu
       for (int i = j + 1; i < M; ++i) a[i * M + j] *= t;
     }
   }
   int first = 0;
-#pragma unroll
+#pragma unroll kUnrollLu
   for (int i = 0; i < M; ++i) {
     // s = x[perm[i]]; x[perm[i]] = x[i];   with perm[i] >= i
     Real s = x[i];
-#pragma unroll
+#pragma unroll kUnrollLu
     for (int r = i + 1; r < M; ++r) {
       if (perm[i] == r) {
         s = x[r];
@@ -234,7 +236,7 @@ LM_HD int lu_solve(const Real *A, const Real *B, Real *x) {
       }
     }
     if (first != 0) {
-#pragma unroll
+#pragma unroll kUnrollLu
       for (int jj = 0; jj < i; ++jj)
         if (jj >= first - 1) s -= a[i * M + jj] * x[jj];
     } else if (s != Real(0.0)) {
@@ -242,10 +244,10 @@ LM_HD int lu_solve(const Real *A, const Real *B, Real *x) {
     }
     x[i] = s;
   }
-#pragma unroll
+#pragma unroll kUnrollLu
   for (int i = M - 1; i >= 0; --i) {
     Real s = x[i];
-#pragma unroll
+#pragma unroll kUnrollLu
     for (int j = i + 1; j < M; ++j) s -= a[i * M + j] * x[j];
     x[i] = s / a[i * M + i];
   }

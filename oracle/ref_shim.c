@@ -141,3 +141,39 @@ void sp_hatfldb_jac(float *p, float *j, int m, int n, void *d)
     j[k * m + k] = -0.5f / sqrtf(p[k]);
   }
 }
+
+/* ---- a wide problem (ours): m up to 16 unknowns, for the host-callback path's m = 9..16 instantiations (levmar takes any m,
+ * lm_core.c:528-548; lmdemo.c's problems stop at m = 5).  hx_i = sum_j p_j T_j(t_i) + 0.05 sin(p_0 t_i), t_i in [-1, 1],
+ * T_j the Chebyshev polynomials; n measurements; nonlinear through the sine only, well conditioned through the basis. */
+void wide_cheb(double *p, double *x, int m, int n, void *d)
+{
+  int i, j;
+  (void)d;
+  for (i = 0; i < n; ++i) {
+    const double t = (n > 1) ? -1.0 + 2.0 * i / (n - 1) : 0.0;
+    double tjm1 = 1.0, tj = t, s = p[0];
+    for (j = 1; j < m; ++j) {
+      const double next = 2.0 * t * tj - tjm1;
+      s += p[j] * tj;
+      tjm1 = tj;
+      tj = next;
+    }
+    x[i] = s + 0.05 * sin(p[0] * t);
+  }
+}
+void wide_cheb_jac(double *p, double *jac, int m, int n, void *d)
+{
+  int i, j;
+  (void)d;
+  for (i = 0; i < n; ++i) {
+    const double t = (n > 1) ? -1.0 + 2.0 * i / (n - 1) : 0.0;
+    double tjm1 = 1.0, tj = t;
+    jac[i * m] = 1.0 + 0.05 * t * cos(p[0] * t);
+    for (j = 1; j < m; ++j) {
+      const double next = 2.0 * t * tj - tjm1;
+      jac[i * m + j] = tj;
+      tjm1 = tj;
+      tj = next;
+    }
+  }
+}

@@ -766,6 +766,37 @@ def test_lmdemo_known_answers_through_the_product_abi(gpu, capfd):
     capfd.readouterr()
 
 
+@pytest.mark.skipif(L.ref is None, reason="the wide problem's callbacks live in oracle/_ref")
+@pytest.mark.parametrize("m", [9, 12, 16])
+def test_wide_problems_through_the_product_abi(gpu, m):
+    """levmar takes any m (lm_core.c:528-548 sizes its scratch by m); the host-callback path instantiates its machines for
+    m = 1..16.  A 12-or-so-parameter Chebyshev fit with a sine in it (oracle/ref_shim.c: wide_cheb, ours) through all four
+    entry points of the product ABI against the compiled reference: n m <= 65536, so the sums are formed in the reference's
+    order and p, info[] and the covariance must be the reference's bit for bit."""
+    torch, brdf_amd, dev = gpu
+    from brdf_amd._lib import lib
+    from tests.kat_problems import run_problem
+    n = 64
+    rng = np.random.default_rng(m)
+    truth = rng.uniform(-1.0, 1.0, m)
+    x = np.zeros(n)
+    L.ref.wide_cheb(L.ptr(truth.copy()), L.ptr(x), m, n, None)
+    x += 1e-3 * (rng.random(n) - 0.5)
+    base = dict(f="wide_cheb", j="wide_cheb_jac", p=[0.1] * m, x=list(x), itmax=200, covar=True)
+    for kind in ("dif", "der", "bc_dif", "bc_der"):
+        pr = dict(base, kind=kind, lb=[-0.75] * m, ub=[0.75] * m)
+        want = run_problem(L.ref, "", pr)
+        got = run_problem(lib, "", pr, ref_lib=L.ref)
+        assert got[0] == want[0] >= 0, (kind, brdf_amd.last_error())
+        assert np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2]), (kind, got[1], want[1])
+        if want[3] is not None and kind in ("dif", "der"):
+            assert np.array_equal(got[3], want[3])
+    p = np.array([0.1] * 17)
+    info = np.zeros(10)
+    assert lib.dlevmar_dif(C.cast(L.ref.wide_cheb, C.c_void_p), L.ptr(p), L.ptr(np.zeros(40)), 17, 40, 10, None, L.ptr(info), None, None, None) == -1
+    assert "m <= 16" in brdf_amd.last_error() or "<= 16" in brdf_amd.last_error()
+
+
 @pytest.mark.skipif(L.ref is None, reason="the float problem functions live in oracle/_ref")
 def test_single_precision_twins_replay_the_reference(gpu, capfd):
     """slevmar_dif / _der / _bc_dif / _bc_der (levmar.h:208-231): the machines and the
