@@ -42,6 +42,13 @@ def _stream_handle(torch):
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# brdf_hip_fit_dev once more, with plain addresses for its pointer arguments: ndarray.ctypes.data_as() costs ~3 us per pointer and a
+# single-fit call passes seven of them -- more host time than the launch itself.  One scratch array per call, one base address.
+_FIT_DEV = C.CFUNCTYPE(C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)(("brdf_hip_fit_dev", lib))
+_OFF_P, _OFF_LB, _OFF_UB, _OFF_DS, _OFF_OPTS, _OFF_INFO, _OFF_COVAR, _SCRATCH = 0, 3, 6, 9, 12, 17, 27, 36
+
+
 def fit_single(method: int, model: int, angles, x, p0, *, lb=None, ub=None, dscl=None, itmax=100, opts=None,
                want_covar=False) -> FitResult:
     """One fit over device-resident samples.  angles: CUDA float64 tensor [3,n] (or [3n]), x: [n].
@@ -49,20 +56,36 @@ def fit_single(method: int, model: int, angles, x, p0, *, lb=None, ub=None, dscl
     Mirrors a dlevmar_dif / dlevmar_bc_dif call (levmar.h:112-127) with the samples already in HBM.
     """
     import torch
-    _require(angles.is_cuda and x.is_cuda and angles.dtype == torch.float64 and x.dtype == torch.float64, "bad argument: " 'angles.is_cuda and x.is_cuda and angles.dtype == torch.float64 and x.dtype == torch.float64')
-    angles = angles.contiguous()
-    x = x.contiguous()
+    _require(angles.is_cuda and x.is_cuda and angles.dtype == torch.float64 and x.dtype == torch.float64, "angles, x: CUDA float64 tensors")
+    if not angles.is_contiguous():
+        angles = angles.contiguous()
+    if not x.is_contiguous():
+        x = x.contiguous()
     n = x.numel()
-    _require(angles.numel() == 3 * n, "bad argument: " 'angles.numel() == 3 * n')
-    p = _f64(p0, 3).copy()
-    info = np.zeros(10)
-    covar = np.zeros(9) if want_covar else None
-    lb_a, ub_a, ds_a, op_a = _f64(lb, 3), _f64(ub, 3), _f64(dscl, 3), _f64(opts, 5)
-    with torch.cuda.device(x.device):
-        ret = lib.brdf_hip_fit_dev(method, model, angles.data_ptr(), x.data_ptr(), n, _dptr(p), _dptr(lb_a),
-                                   _dptr(ub_a), _dptr(ds_a), itmax, _dptr(op_a), _dptr(info), _dptr(covar),
-                                   _stream_handle(torch))
-    return FitResult(ret, p, info, None if covar is None else covar.reshape(3, 3))
+    _require(angles.numel() == 3 * n, "angles must hold 3 planes of x.numel() doubles")
+    buf = np.zeros(_SCRATCH)  # p | lb | ub | dscl | opts | info | covar: the call's host arguments and results
+    base = buf.ctypes.data
+
+    def put(off, v, size):
+        if v is None:
+            return None
+        a = np.asarray(v, dtype=np.float64).reshape(-1)
+        _require(a.size == size, f"expected {size} values, got {a.size}")
+        buf[off:off + size] = a
+        return base + 8 * off
+
+    p_ptr = put(_OFF_P, p0, 3)
+    _require(p_ptr is not None, "p0 is required")
+    args = (method, model, angles.data_ptr(), x.data_ptr(), n, p_ptr, put(_OFF_LB, lb, 3), put(_OFF_UB, ub, 3), put(_OFF_DS, dscl, 3), itmax,
+            put(_OFF_OPTS, opts, 5), base + 8 * _OFF_INFO, (base + 8 * _OFF_COVAR) if want_covar else None)
+    dev = x.device
+    if torch.cuda.current_device() == (dev.index if dev.index is not None else torch.cuda.current_device()):
+        ret = _FIT_DEV(*args, torch.cuda.current_stream().cuda_stream)
+    else:
+        with torch.cuda.device(dev):
+            ret = _FIT_DEV(*args, torch.cuda.current_stream().cuda_stream)
+    return FitResult(ret, buf[_OFF_P:_OFF_P + 3].copy(), buf[_OFF_INFO:_OFF_INFO + 10].copy(),
+                     buf[_OFF_COVAR:_OFF_COVAR + 9].reshape(3, 3).copy() if want_covar else None)
 
 
 def fit_channels(method: int, model: int, angles, x, p0, *, lb=None, ub=None, dscl=None, itmax=100, opts=None, want_covar=False):

@@ -52,8 +52,8 @@ def test_argument_errors_return_lm_error_without_a_gpu(capfd):
 
     fptr = C.cast(user_func, C.c_void_p)
     # an unregistered callback is legal (generic path: host evaluates it); too many parameters is refused up front
-    rc = lib.dlevmar_dif(fptr, np.zeros(9).ctypes.data_as(D), x.ctypes.data_as(D), 9, 10, 100, None, None, None, None, None)
-    assert rc == -1 and "1 <= m <= 8" in brdf_amd.last_error()
+    rc = lib.dlevmar_dif(fptr, np.zeros(17).ctypes.data_as(D), np.zeros(20).ctypes.data_as(D), 17, 20, 100, None, None, None, None, None)
+    assert rc == -1 and "1 <= m <= 16" in brdf_amd.last_error()
     hip = C.cast(lib.BRDFFunc_hip, C.c_void_p)
     rc = lib.dlevmar_dif(hip, p.ctypes.data_as(D), x.ctypes.data_as(D), 4, 10, 100, None, None, None, None, C.byref(ed))
     assert rc == -1 and "exactly 3 parameters" in brdf_amd.last_error()
