@@ -256,14 +256,32 @@ __global__ __launch_bounds__(kStreamThreads, kStreamWavesPerSimd) void stream_pa
     break;
   case RQ_EVAL_MULTI:  // several projected-gradient candidates share one sweep (lm_machine.h, BcMachine::Cold::multi)
     SWEEP_BEGIN(4)
+    if (u.ncand == kMaxCand) {  // the usual case: no guard between a sample's candidates, four independent exp chains per basic
+                                // block (resident_fit_impl.h, RQ_EVAL_MULTI)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < 4; ++k) {
 #pragma unroll
-      for (int j = 0; j < kMaxCand; ++j)
-        if (j < u.ncand) {
-          const double e = ok[k] ? sx[k] - model_value_k<MODEL, FAST>(u, j, s0[k], pq[k]) : 0.0;
-          acc[j] += e * e;
+        for (int j0 = 0; j0 < kMaxCand; j0 += 4) {
+          double e[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) e[j] = sx[k] - model_value_k<MODEL, FAST>(u, j0 + j, s0[k], pq[k]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (!ok[k]) e[j] = 0.0;
+            acc[j0 + j] += e[j] * e[j];
+          }
         }
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int j = 0; j < kMaxCand; ++j)
+          if (j < u.ncand) {
+            const double e = ok[k] ? sx[k] - model_value_k<MODEL, FAST>(u, j, s0[k], pq[k]) : 0.0;
+            acc[j] += e * e;
+          }
+      }
     }
     SWEEP_END
     STAMP();
@@ -283,17 +301,30 @@ __global__ __launch_bounds__(kStreamThreads, kStreamWavesPerSimd) void stream_pa
     break;
   case RQ_JAC:
     SWEEP_BEGIN(4)
+    {  // (the row's kind is chosen per batch of four samples, outside their bodies: straight-line bodies, see resident_fit_impl.h RQ_JAC)
+      auto rows = [&](auto jk) {
+        constexpr int JK = decltype(jk)::value;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      double f0 = 0.0, j[kM];
-      if (u.analytic)  // dlevmar_bc_der: the caller's jacf is the model's own analytic Jacobian (lmbc_core.c:578)
-        model_an_row<MODEL, FAST>(u, s0[k], pq[k], f0, j);
+        for (int k = 0; k < 4; ++k) {
+          double f0 = 0.0, j[kM];
+          if (JK == 2)  // dlevmar_bc_der: the caller's jacf is the model's own analytic Jacobian (lmbc_core.c:578)
+            model_an_row<MODEL, FAST>(u, s0[k], pq[k], f0, j);
+          else if (JK == 1)
+            model_fd_row_t<MODEL, FAST, true>(u, s0[k], pq[k], true, f0, 0.0, false, j);
+          else
+            model_fd_row_t<MODEL, FAST, false>(u, s0[k], pq[k], true, f0, 0.0, false, j);
+          double e = sx[k] - f0;
+          if (!ok[k]) e = j[0] = j[1] = j[2] = 0.0;
+          acc_normal_eq(j, e, acc, acc + kNL);
+          acc[kNL + kM] += e * e;
+        }
+      };
+      if (u.analytic)
+        rows(std::integral_constant<int, 2>{});
+      else if (u.central)
+        rows(std::integral_constant<int, 1>{});
       else
-        model_fd_row<MODEL, FAST>(u, s0[k], pq[k], true, f0, 0.0, false, j);
-      double e = sx[k] - f0;
-      if (!ok[k]) e = j[0] = j[1] = j[2] = 0.0;
-      acc_normal_eq(j, e, acc, acc + kNL);
-      acc[kNL + kM] += e * e;
+        rows(std::integral_constant<int, 0>{});
     }
     SWEEP_END
     STAMP();
