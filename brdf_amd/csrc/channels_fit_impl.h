@@ -51,6 +51,7 @@ struct ChannelsCtx {
   unsigned tag_base[kMaxChannels];
   long long spin_ticks;
   int replicas;
+  int sabotage_epoch;  // test hook (BRDF_HIP_RESIDENT_SABOTAGE): the last workgroup withholds its rows at this epoch; -1 = never
 };
 
 // what control_exchange() / gather_block() read of a context, for one channel
@@ -215,8 +216,8 @@ __global__ __launch_bounds__(kRThreads) void channels_fit_kernel(ChannelsCtx ctx
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     const ChannelView view{ctx.rows + (size_t)c * kRowsGranules, ctx.groups + (size_t)c * kGroupsGranules, ctx.ctl, ctx.launch_id,
-                           c == 0 ? ctx.tag_base[0] : (c == 1 ? ctx.tag_base[1] : ctx.tag_base[2]), ctx.spin_ticks, -1, ctx.replicas,
-                           nullptr, -1};
+                           c == 0 ? ctx.tag_base[0] : (c == 1 ? ctx.tag_base[1] : ctx.tag_base[2]), ctx.spin_ticks, ctx.sabotage_epoch,
+                           ctx.replicas, nullptr, -1};
     long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long last_ = 0;
     long long n_jac = 0;
@@ -619,6 +620,8 @@ int channels_attempt(const ChannelsArgs &a, CWorkspace &ws, bool *retry_exact, b
   c.replicas = kReplicas;
   if (const char *e = getenv("BRDF_HIP_RESIDENT_REPLICAS")) c.replicas = std::min(kReplicas, std::max(1, atoi(e)));
   if (const char *e = getenv("BRDF_HIP_RESIDENT_SPIN_MS")) c.spin_ticks = std::max(1LL, atoll(e)) * 100000LL;
+  c.sabotage_epoch = -1;
+  if (const char *e = getenv("BRDF_HIP_RESIDENT_SABOTAGE")) c.sabotage_epoch = atoi(e);  // tests only: forces the fallback
   {  // one workgroup per CU must be able to live there at all (registers, LDS): checked once per kernel
     static int per_cu = -1;
     if (per_cu < 0 && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, channels_fit_kernel<MODEL, FAST>, kRThreads, 0) != hipSuccess) per_cu = 0;

@@ -335,6 +335,33 @@ def test_channels_sharing_a_launch_equal_single_fits_bit_for_bit(gpu, model, n):
             assert np.array_equal(res[c].p, alone.p) and np.array_equal(res[c].info, alone.info)
 
 
+def test_channel_launch_drains_when_a_workgroup_never_arrives(gpu, monkeypatch):
+    """every wait of the shared-launch kernel is bounded too: with one workgroup withholding its rows (test hook) the control
+    waves give up, the sweeping waves see the workgroup's abort word, the launch drains, and the call fits its channels one after the
+    other -- through the single-fit regimes, which are sabotaged as well and end in the launch chain: same answers, no hang"""
+    torch, brdf_amd, dev = gpu
+    monkeypatch.setenv("BRDF_HIP_RESIDENT_SABOTAGE", "3")
+    monkeypatch.setenv("BRDF_HIP_RESIDENT_SPIN_MS", "20")
+    monkeypatch.setenv("BRDF_HIP_RESIDENT_BACKOFF", "0")
+    model, n = 2, 100000
+    lb, ub = synth.bounds(model)  # (Ward's roughness kept off 0: the third channel would otherwise end in levmar's NaN stop, here as in the reference)
+    angles, _, _ = synth.make_single(model, n)
+    xs = _channel_measurements(model, angles, n)
+    a = torch.from_numpy(np.ascontiguousarray(angles)).to(dev)
+    xd = torch.from_numpy(np.ascontiguousarray(xs)).to(dev)
+    res = brdf_amd.fit_channels(1, model, a, xd, synth.P0[model], lb=lb, ub=ub, itmax=synth.ITMAX, opts=synth.OPTS)
+    assert not brdf_amd.last_channels_stats(3)["shared_launch"]
+    for c in range(3):
+        _, p_ref, info_ref = L.brdf_fit("orc", 1, model, angles, xs[c], synth.P0[model], synth.ITMAX, synth.OPTS, lb, ub)
+        _check(res[c], p_ref, info_ref)
+    monkeypatch.delenv("BRDF_HIP_RESIDENT_SABOTAGE")
+    res = brdf_amd.fit_channels(1, model, a, xd, synth.P0[model], lb=lb, ub=ub, itmax=synth.ITMAX, opts=synth.OPTS)
+    assert brdf_amd.last_channels_stats(3)["shared_launch"]  # and the shared launch works again afterwards (tables restarted)
+    for c in range(3):
+        _, p_ref, info_ref = L.brdf_fit("orc", 1, model, angles, xs[c], synth.P0[model], synth.ITMAX, synth.OPTS, lb, ub)
+        _check(res[c], p_ref, info_ref)
+
+
 # ---- batched regime ------------------------------------------------------------------------------------
 def _batch(gpu, method, model, angles, x, p0):
     torch, brdf_amd, dev = gpu
