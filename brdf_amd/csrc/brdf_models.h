@@ -260,8 +260,8 @@ LM_HD double model_value_k(const PassUniforms<MODEL> &u, int j, double c0, const
 }
 
 // f(q) for one sample (dif trial point)
-template <int MODEL, bool FAST>
-LM_HD double model_value_q(const PassUniforms<MODEL> &u, double c0, const Prep &q) {
+template <int MODEL, bool FAST, class U>
+LM_HD double model_value_q(const U &u, double c0, const Prep &q) {
   using Mdl = BrdfModel<MODEL>;
   return Mdl::combine(u.lq, c0, Mdl::template shape<FAST>(u.nq, c0, q));
 }

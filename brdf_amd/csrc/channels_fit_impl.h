@@ -65,15 +65,6 @@ struct ChannelView {
   int trace_epoch;
 };
 
-// a wave-uniform value (read from LDS into a vector register) moved into scalar registers
-__device__ __forceinline__ double scalar_copy(double v) {
-  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
-  const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ Lin scalar_copy(const Lin &l) { return Lin{scalar_copy(l.a), scalar_copy(l.b)}; }
-__device__ __forceinline__ Nl scalar_copy(const Nl &n) { return Nl{scalar_copy(n.u0), scalar_copy(n.u1)}; }
-
 // what an evaluation / a Jacobian pass reads of a request's uniforms (PassUniforms<MODEL>'s field names: the model functions of
 // brdf_models.h take either), small enough to live in scalar registers for a sweep
 struct EvalUniforms {

@@ -121,6 +121,15 @@ __device__ __forceinline__ void fold_rows(const double *v, double *buf, double *
   block_reduce<NS, THREADS>(v, v[kSums], buf, out);
 }
 
+// a wave-uniform value (read from LDS into a vector register) moved into scalar registers
+__device__ __forceinline__ double scalar_copy(double v) {
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+  const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ Lin scalar_copy(const Lin &l) { return Lin{scalar_copy(l.a), scalar_copy(l.b)}; }
+__device__ __forceinline__ Nl scalar_copy(const Nl &n) { return Nl{scalar_copy(n.u0), scalar_copy(n.u1)}; }
+
 // ---- the nine sums of a dlevmar_dif trial sweep (resident_fit.hip explains them where they are accumulated) -------------
 constexpr int kTrialSums = 3 + 2 * kM;  // what a dlevmar_dif trial sweep reduces: [e'^2, J^T t (3), t^T t, J'^T e' (3), t^T e]
 

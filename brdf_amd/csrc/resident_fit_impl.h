@@ -582,6 +582,26 @@ __device__ __forceinline__ void sweep_pass(int kind, const PassUniforms<MODEL> &
     break;
   case RQ_DIF_TRIAL:  // speculative protocol: the Broyden-updated row is formed for the sums only (see the file comment)
     if constexpr (METHOD == 0) {
+#ifndef BRDF_EXP_LDS_UNIFORMS
+      // The pass's uniforms live in LDS (the control wave builds them there); read through `su`, the sweep keeps them in VECTOR
+      // registers, and every use of one in an fp64 instruction then costs a register, a copy or an operand slot.  Copied into
+      // SCALAR registers once per sweep (readfirstlane: they are wave-uniform) the same loop runs 2.4x faster in isolation
+      // (scripts/micro/trial_sweep.hip: 2.0k against 4.9k ticks per sweep of eight samples at two waves per SIMD).
+      struct TrialUniforms {
+        Lin lq;
+        Nl nq;
+        double dp[kM], dp_l2;
+      };
+      TrialUniforms tu;
+      tu.lq = scalar_copy(u.lq);
+      tu.nq = scalar_copy(u.nq);
+#pragma unroll
+      for (int j = 0; j < kM; ++j) tu.dp[j] = scalar_copy(u.dp[j]);
+      tu.dp_l2 = scalar_copy(u.dp_l2);
+      const double dpp_s[kM] = {scalar_copy(dpp[0]), scalar_copy(dpp[1]), scalar_copy(dpp[2])};
+      const TrialUniforms &u = tu;  // (shadows the LDS uniforms for the rest of this case)
+      const double *dpp = dpp_s;
+#endif
       const double rinv = 1.0 / u.dp_l2;
       auto value_q = [&](int k) { return model_value_q<MODEL, FAST>(u, st.get(kFc0, k), prep(k)); };
       auto body = [&](auto pend_c, int k, const double w) {
@@ -853,8 +873,29 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
         double mx = 0.0;
         const double dpp[kM] = {dp_prev[0], dp_prev[1], dp_prev[2]};
         if constexpr (kControlFromLds) {
+#ifndef BRDF_EXP_CONTROL_REGS
           decisions(ls, pend);
           sweep_pass<MODEL, METHOD, FAST, !BATCHED>(kind, su, ls, jl, tid, nk, nfull, okm, pend, dpp, acc, mx);
+#else
+          // (measured and lost, -DBRDF_EXP_CONTROL_REGS: the parked samples brought into registers for the sweep by one burst of ds_reads,
+          // the other waves' unrolled register sweep, what the pass changed parked again.  The rolled LDS loop below pays the LDS latency
+          // of a sample's seven fields -- 7.0k ticks per sweep against the register waves' ~5k -- but the burst variant spills 46 VGPRs
+          // inside the sweep: 480 against 425 us per 10^6-sample fit.)
+#pragma unroll
+          for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int k = 0; k < kRSpt; ++k) rs.v[f][k] = ls.get(f, k);
+          decisions(rs, pend);
+          sweep_pass<MODEL, METHOD, FAST, !BATCHED>(kind, su, rs, jl, tid, nk, nfull, okm, pend, dpp, acc, mx);
+          if constexpr (METHOD == 0) {
+#pragma unroll
+            for (int k = 0; k < kRSpt; ++k) {
+              ls.set(kFhx, k, rs.v[kFhx][k]);
+              ls.set(kFwrk, k, rs.v[kFwrk][k]);
+              ls.set(kFtb, k, rs.v[kFtb][k]);
+            }
+          }
+#endif
         } else {
           decisions(rs, pend);
           sweep_pass<MODEL, METHOD, FAST, !BATCHED>(kind, su, rs, jl, tid, nk, nfull, okm, pend, dpp, acc, mx);
