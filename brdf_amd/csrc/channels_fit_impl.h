@@ -65,20 +65,6 @@ struct ChannelView {
   int trace_epoch;
 };
 
-// what an evaluation / a Jacobian pass reads of a request's uniforms (PassUniforms<MODEL>'s field names: the model functions of
-// brdf_models.h take either), small enough to live in scalar registers for a sweep
-struct EvalUniforms {
-  Lin l0;
-  Nl n0;
-  double scal;
-};
-struct JacUniforms {
-  Lin l0, lp[kM], lm[kM];
-  Nl n0, np2, nm2;
-  double dinv[kM], an[2];
-  int central, analytic;
-};
-
 __device__ __forceinline__ unsigned lds_load(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lds_store(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 

@@ -130,6 +130,20 @@ __device__ __forceinline__ double scalar_copy(double v) {
 __device__ __forceinline__ Lin scalar_copy(const Lin &l) { return Lin{scalar_copy(l.a), scalar_copy(l.b)}; }
 __device__ __forceinline__ Nl scalar_copy(const Nl &n) { return Nl{scalar_copy(n.u0), scalar_copy(n.u1)}; }
 
+// what an evaluation / a Jacobian pass reads of a request's uniforms (PassUniforms<MODEL>'s field names: the model functions of
+// brdf_models.h take either), small enough to live in scalar registers for a sweep
+struct EvalUniforms {
+  Lin l0;
+  Nl n0;
+  double scal;
+};
+struct JacUniforms {
+  Lin l0, lp[kM], lm[kM];
+  Nl n0, np2, nm2;
+  double dinv[kM], an[2];
+  int central, analytic;
+};
+
 // ---- the nine sums of a dlevmar_dif trial sweep (resident_fit.hip explains them where they are accumulated) -------------
 constexpr int kTrialSums = 3 + 2 * kM;  // what a dlevmar_dif trial sweep reduces: [e'^2, J^T t (3), t^T t, J'^T e' (3), t^T e]
 

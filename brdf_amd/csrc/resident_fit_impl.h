@@ -453,8 +453,9 @@ __device__ __forceinline__ void sweep_pass(int kind, const PassUniforms<MODEL> &
   switch (kind) {
   case RQ_EVAL:  // (the four kinds only dlevmar_bc_dif / bc_der / der issue are compiled into those kernels only)
     if constexpr (METHOD != 0) {
+      const EvalUniforms eu{scalar_copy(u.l0), scalar_copy(u.n0), 1.0};  // (scalar registers: see RQ_DIF_TRIAL)
       for_bc([&](int k) {
-        const double f = model_value<MODEL, FAST>(u, st.get(kFc0, k), prep(k));
+        const double f = model_value<MODEL, FAST>(eu, st.get(kFc0, k), prep(k));
         double e = st.get(kFx, k) - f;
         if (dead(k)) e = 0.0;
         acc[0] = fma(e, e, acc[0]);
@@ -464,9 +465,10 @@ __device__ __forceinline__ void sweep_pass(int kind, const PassUniforms<MODEL> &
     break;
   case RQ_SCALED:
     if constexpr (METHOD != 0) {
+      const EvalUniforms eu{scalar_copy(u.l0), scalar_copy(u.n0), scalar_copy(u.scal)};
       for_bc([&](int k) {
-        const double f = model_value<MODEL, FAST>(u, st.get(kFc0, k), prep(k));
-        double t = (st.get(kFx, k) - f) / u.scal;
+        const double f = model_value<MODEL, FAST>(eu, st.get(kFc0, k), prep(k));
+        double t = (st.get(kFx, k) - f) / eu.scal;
         if (dead(k)) t = 0.0;
         acc[0] = fma(t, t, acc[0]);
       });
@@ -479,22 +481,51 @@ __device__ __forceinline__ void sweep_pass(int kind, const PassUniforms<MODEL> &
         // the usual case, a full set of candidates: no `j < ncand` guard between the candidates of a sample, so that four
         // independent exp chains share a basic block and interleave (guarded, every candidate is a block of its own and its
         // chain runs alone: scripts/micro/exp_ilp.hip measures 76 cycles per exp and SIMD that way, 51 with four side by side)
-        for_samples<U>(nk, [&](int k) {
-          const double c0 = st.get(kFc0, k), x = st.get(kFx, k);
-          const Prep q = prep(k);
-          const bool d = dead(k);
+        if constexpr (METHOD == 0) {  // (the dlevmar_dif kernels have no register to spare: sample by sample, uniforms read from LDS;
+                                      // the group-major form below cost them 24 us per 10^6-sample fit)
+          for_samples<U>(nk, [&](int k) {
+            const double c0 = st.get(kFc0, k), x = st.get(kFx, k);
+            const Prep q = prep(k);
+            const bool d = dead(k);
 #pragma unroll
-          for (int j0 = 0; j0 < kMaxCand; j0 += 4) {
+            for (int j0 = 0; j0 < kMaxCand; j0 += 4) {
+              double e[4];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) e[j] = x - model_value_k<MODEL, FAST>(u, j0 + j, c0, q);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                if (d) e[j] = 0.0;
+                acc[j0 + j] = fma(e[j], e[j], acc[j0 + j]);
+              }
+            }
+          });
+          break;
+        }
+        // ... four candidates at a time over ALL samples, their uniforms (sixteen doubles) in scalar registers for that sweep (see
+        // RQ_DIF_TRIAL); every candidate's sum still takes its samples in slot order: configs[3] dlevmar_bc_dif 0.93 -> 0.84 s
+#pragma unroll
+        for (int j0 = 0; j0 < kMaxCand; j0 += 4) {
+          Lin l4[4];
+          Nl n4[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            l4[j] = scalar_copy(u.lk[j0 + j]);
+            n4[j] = scalar_copy(u.nk[j0 + j]);
+          }
+          for_samples<U>(nk, [&](int k) {
+            const double c0 = st.get(kFc0, k), x = st.get(kFx, k);
+            const Prep q = prep(k);
+            const bool d = dead(k);
             double e[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) e[j] = x - model_value_k<MODEL, FAST>(u, j0 + j, c0, q);
+            for (int j = 0; j < 4; ++j) e[j] = x - BrdfModel<MODEL>::combine(l4[j], c0, BrdfModel<MODEL>::template shape<FAST>(n4[j], c0, q));  // model_value_k()
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               if (d) e[j] = 0.0;
               acc[j0 + j] = fma(e[j], e[j], acc[j0 + j]);
             }
-          }
-        });
+          });
+        }
         break;
       }
 #endif
@@ -519,14 +550,32 @@ __device__ __forceinline__ void sweep_pass(int kind, const PassUniforms<MODEL> &
       // scripts/micro/exp_ilp.hip: a lone dependent exp chain takes 237 cycles per exp on a wave, two interleaved 110 each).
       auto jac = [&](auto jk) {
         constexpr int JK = decltype(jk)::value;
+        JacUniforms ju;  // the fields this kind of row reads, in scalar registers for the sweep (see RQ_DIF_TRIAL)
+        ju.l0 = scalar_copy(u.l0);
+        ju.n0 = scalar_copy(u.n0);
+        ju.analytic = JK == 2;
+        ju.central = JK == 1;
+        if (JK == 2) {
+          ju.an[0] = scalar_copy(u.an[0]);
+          ju.an[1] = scalar_copy(u.an[1]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < kM; ++j) {
+            ju.lp[j] = scalar_copy(u.lp[j]);
+            ju.dinv[j] = scalar_copy(u.dinv[j]);
+            if (JK == 1) ju.lm[j] = scalar_copy(u.lm[j]);
+          }
+          ju.np2 = scalar_copy(u.np2);
+          if (JK == 1) ju.nm2 = scalar_copy(u.nm2);
+        }
         for_bc([&](int k) {
           double f0 = 0.0, j[kM];
           if (JK == 2)
-            model_an_row<MODEL, FAST>(u, st.get(kFc0, k), prep(k), f0, j);
+            model_an_row<MODEL, FAST>(ju, st.get(kFc0, k), prep(k), f0, j);
           else if (JK == 1)
-            model_fd_row_t<MODEL, FAST, true>(u, st.get(kFc0, k), prep(k), true, f0, 0.0, false, j);
+            model_fd_row_t<MODEL, FAST, true>(ju, st.get(kFc0, k), prep(k), true, f0, 0.0, false, j);
           else
-            model_fd_row_t<MODEL, FAST, false>(u, st.get(kFc0, k), prep(k), true, f0, 0.0, false, j);
+            model_fd_row_t<MODEL, FAST, false>(ju, st.get(kFc0, k), prep(k), true, f0, 0.0, false, j);
           double e = st.get(kFx, k) - f0;
           if (dead(k)) e = j[0] = j[1] = j[2] = 0.0;
           acc_normal_eq_fma(j, e, acc, acc + kNL);
