@@ -338,6 +338,15 @@ __global__ __launch_bounds__(kRThreads) void channels_fit_kernel(ChannelsCtx ctx
       // compiler, every sample re-read them one by one -- ten ds_reads and nine waits per Jacobian row; held in registers for the
       // whole sweep, they push the sixteen resident samples' registers into scratch: 229-425 spilled VGPRs in every variant tried).
       auto sweep = [&](auto &&load, auto &&body) {
+#ifdef BRDF_EXP_CHANNEL_SCALAR
+        const auto u = scalar_copy(load());
+#pragma unroll
+        for (int k = 0; k < kRSpt; ++k)
+          if (k < nk) {
+            body(u, 0, k);
+            body(u, 1, k);
+          }
+#else
 #pragma unroll
         for (int k = 0; k < kRSpt; ++k)
           if (k < nk) {
@@ -346,6 +355,7 @@ __global__ __launch_bounds__(kRThreads) void channels_fit_kernel(ChannelsCtx ctx
             body(u, 0, k);
             body(u, 1, k);
           }
+#endif
       };
       switch (kind) {
       case RQ_EVAL:

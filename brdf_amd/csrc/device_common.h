@@ -144,6 +144,28 @@ struct JacUniforms {
   int central, analytic;
 };
 
+__device__ __forceinline__ EvalUniforms scalar_copy(const EvalUniforms &u) { return EvalUniforms{scalar_copy(u.l0), scalar_copy(u.n0), scalar_copy(u.scal)}; }
+__device__ __forceinline__ JacUniforms scalar_copy(const JacUniforms &u) {  // (only the fields its `analytic` / `central` say are set)
+  JacUniforms r;
+  r.l0 = scalar_copy(u.l0);
+  r.n0 = scalar_copy(u.n0);
+  r.analytic = u.analytic;
+  r.central = u.central;
+  if (u.analytic) {
+    r.an[0] = scalar_copy(u.an[0]);
+    r.an[1] = scalar_copy(u.an[1]);
+  } else {
+    for (int j = 0; j < kM; ++j) {
+      r.lp[j] = scalar_copy(u.lp[j]);
+      r.dinv[j] = scalar_copy(u.dinv[j]);
+      if (u.central) r.lm[j] = scalar_copy(u.lm[j]);
+    }
+    r.np2 = scalar_copy(u.np2);
+    if (u.central) r.nm2 = scalar_copy(u.nm2);
+  }
+  return r;
+}
+
 // ---- the nine sums of a dlevmar_dif trial sweep (resident_fit.hip explains them where they are accumulated) -------------
 constexpr int kTrialSums = 3 + 2 * kM;  // what a dlevmar_dif trial sweep reduces: [e'^2, J^T t (3), t^T t, J'^T e' (3), t^T e]
 
