@@ -77,6 +77,10 @@ __global__ __launch_bounds__(kWave, W) void lane_fit_kernel(BatchCtx ctx, int *q
   const double *ub = ctx.has_ub ? ubv : nullptr;
 
   BcMachine<kM> m;
+  // the half of the machine every fit of the batch shares is configured once, here, in wave-uniform control flow: options,
+  // box and limits then live in scalar registers instead of 64 identical per-lane copies
+  m.configure(n, lb, ub, nullptr, ctx.itmax, opts, 0, 1);
+  m.c.analytic_jac = ctx.analytic;
   m.h.req.kind = RQ_DONE;
   int fit = -1;
   bool more = true;  // wave-uniform: the queue may still hold fits
@@ -98,6 +102,11 @@ __global__ __launch_bounds__(kWave, W) void lane_fit_kernel(BatchCtx ctx, int *q
   // for all of them together once a quorum waits (or nobody has anything else to do, or a lane has waited long enough).
   // Light rounds then cost an evaluation sweep plus the cheap phases only.  Scheduling cannot change a result.
   for (;;) {
+    // a fit's results are written by the step that ends it and stored right behind that step (below): nothing of them
+    // is carried from one round to the next, and saying so keeps 2 x 20 registers per lane free between the two
+    for (int i = 0; i < kInfoSz; ++i) m.c.info[i] = 0.0;
+    for (int i = 0; i < kM * kM; ++i) m.c.covar[i] = 0.0;
+    m.c.ret = kLmError;
     const int kind0 = (fit >= 0) ? m.h.req.kind : (int)RQ_DONE;
     const bool wants_heavy = (fit < 0 && more) || kind0 == RQ_JAC || kind0 == RQ_YIELD;
     const bool light_work = fit >= 0 && kind0 != RQ_JAC && kind0 != RQ_YIELD;
@@ -142,8 +151,7 @@ __global__ __launch_bounds__(kWave, W) void lane_fit_kernel(BatchCtx ctx, int *q
           if (FAST) ctx.flags[f] = bad ? kNeedsExact : 0;
           if (!(FAST && bad)) {
             const double p0[kM] = {ctx.p[(size_t)f * kM], ctx.p[(size_t)f * kM + 1], ctx.p[(size_t)f * kM + 2]};
-            m.start(p0, n, lb, ub, nullptr, ctx.itmax, opts, 0, 1);
-            m.c.analytic_jac = ctx.analytic;
+            m.begin(p0);
             if (m.h.req.kind == RQ_DONE) {  // refused by start() (n < m, inconsistent box): lmbc_core.c:440-454
               if (ctx.ret) ctx.ret[f] = kLmError;
               if (ctx.info)
@@ -186,16 +194,16 @@ __global__ __launch_bounds__(kWave, W) void lane_fit_kernel(BatchCtx ctx, int *q
           // two rows per trip (one wave per SIMD: nothing else hides a row's dependent exp chains), accumulated in the
           // reference's order all the same
           int l = n;
-          for (; l >= 2; l -= 2) {
+          for (; W == 1 && l >= 2; l -= 2) {
             double ea, eb, ja[kM], jb[kM];
             row(l - 1, ea, ja);
             row(l - 2, eb, jb);
             acc_normal_eq(ja, ea, s, s + kNL);
             acc_normal_eq(jb, eb, s, s + kNL);
           }
-          if (l == 1) {
+          for (; l >= 1; --l) {  // (two waves per SIMD hide each other's chains: one row per trip, fewer registers)
             double ea, ja[kM];
-            row(0, ea, ja);
+            row(l - 1, ea, ja);
             acc_normal_eq(ja, ea, s, s + kNL);
           }
           do_step = true;

@@ -73,8 +73,10 @@ enum ReqKind : int {
                      //   aux (step accepted) else x-hx; finally hx <- wrk if aux
   RQ_EVAL_MULTI = 8, // sums[j] = sum (x-f(pk[j]))^2 for j < nk: several candidates of a projected-gradient search
                      //   in ONE sweep (the samples are read once; a pass's fixed cost is paid once)
-  RQ_YIELD = 9       // no pass: a GATED step (BcMachine::run) stopped in front of an expensive phase; call step() again
+  RQ_YIELD = 9,      // no pass: a GATED step (BcMachine::run) stopped in front of an expensive phase; call step() again
                      //   with heavy = true (lane_fit.hip runs the expensive phases of its 64 machines in common rounds)
+  RQ_DIF_INIT_JAC = 10  // RQ_DIF_INIT and the RQ_DIF_JAC of the first iteration in ONE sweep (DifMachine::Cold::fuse_init):
+                     //   hx[sel_hx] <- f(p); J[sel_j] <- FD Jacobian at p; sums = [JtJ lower, Jte, sum e^2]
 };
 
 constexpr int kMaxCand = 8;  // candidates per RQ_EVAL_MULTI
@@ -118,6 +120,7 @@ struct SumLayout {
   static constexpr int NL = M * (M + 1) / 2;
   static constexpr int JAC = NL + M + 1;          // RQ_JAC
   static constexpr int DIF_JAC = NL + M;          // RQ_DIF_JAC
+  static constexpr int DIF_INIT_JAC = NL + M + 1; // RQ_DIF_INIT_JAC
   static constexpr int DIF_TRIAL = 1 + NL + 2 * M;  // RQ_DIF_TRIAL
   static constexpr int MAX = DIF_TRIAL > JAC ? DIF_TRIAL : JAC;
 };
@@ -203,6 +206,8 @@ LM_HD int lu_solve(const Real *A, const Real *B, Real *x) {
       }
     }
     // exchange rows j and pivot (pivot >= j); scale[pivot] <- scale[j]
+    // (measured: a wave-level "does any lane exchange this row" guard in front of these selects changes nothing -- 2,465 against
+    // 2,463 cycles per solve in the resident dlevmar_dif kernel: the solve is bound by its chain of eight divisions)
 #pragma unroll kUnrollLu
     for (int r = j + 1; r < M; ++r) {
       if (pivot == r) {
@@ -351,6 +356,11 @@ struct DifMachine {
                       //   most of the passes.  RQ_EVAL_MULTI evaluates them in one sweep; they are judged in the reference's order,
                       //   only the judged ones are counted, and a candidate that reduces the error is evaluated again by the plain
                       //   trial pass (which forms the Broyden sums): p, info[] and the trajectory are those of one trial at a time.
+    int fuse_init;    // 1: the first pass is RQ_DIF_INIT_JAC -- f(p0) and the finite-difference Jacobian the first iteration opens
+                      //   with (lm_core.c:551-564, then :578-588 at the same point: nu = 20 > 16 forces it) in one sweep.  The
+                      //   evaluation's sum of squares comes out of the Jacobian sweep bit for bit (same residuals, same order).
+                      //   If the fit stops in front of its first iteration (itmax = 0, ||e||^2 <= eps3, a non-finite start)
+                      //   the Jacobian is discarded and never counted: info[] and p are those of the two-pass start.
     Real info[kInfoSz], covar[M * M];
     int ret;
   };
@@ -396,11 +406,13 @@ struct DifMachine {
   Cold c;
   Hot h;
 
-  LM_HD void start(const Real *p0, int n_, int itmax_, const Real *opts, int want_covar_, int speculative_ = 1, int multi_ = 1) {
+  LM_HD void start(const Real *p0, int n_, int itmax_, const Real *opts, int want_covar_, int speculative_ = 1, int multi_ = 1,
+                   int fuse_init_ = 0) {
     Request<M, Real> &req = h.req;
     Cool &cool = h.cool;
     c.o = make_options(opts);
     c.speculative = speculative_;
+    c.fuse_init = (fuse_init_ && speculative_) ? 1 : 0;
     c.multi = (multi_ < 1 || !speculative_) ? 1 : ((multi_ > kMaxCand) ? kMaxCand : multi_);
     h.chain = h.single = h.mcnt = 0;
     for (int j = 0; j < kMaxCand; ++j) cool.ml2[j] = Real(0.0);
@@ -435,6 +447,11 @@ struct DifMachine {
     }
     req.kind = RQ_DIF_INIT;
     for (int i = 0; i < M; ++i) req.p[i] = h.p[i];
+    if (c.fuse_init) {
+      req.kind = RQ_DIF_INIT_JAC;
+      req.central = !c.o.forward;
+      fd_steps<M>(h.p, c.o.delta, req.d);
+    }
     h.phase = D_INIT_EVAL;
   }
 
@@ -478,11 +495,30 @@ struct DifMachine {
       }
       LM_PHASE(D_INIT_EVAL) {  // lm_core.c:551-564
         h.nfev = 1;
-        h.p_e2 = s[0];
+        h.p_e2 = c.fuse_init ? s[SumLayout<M>::DIF_INIT_JAC - 1] : s[0];
         cool.init_e2 = h.p_e2;
         if (!lm_finite(h.p_e2)) h.stop = 7;
         h.nu = 20;
         ph = D_ITER_TOP;
+        if (c.fuse_init) {  // the top of iteration 0 (D_ITER_TOP below), whose Jacobian pass this sweep already was
+          if (!(h.k < c.itmax && !h.stop)) {
+            ph = D_FINISH;
+            break;
+          }
+          if (h.p_e2 <= c.o.eps3) {
+            h.stop = 6;
+            ph = D_FINISH;
+            break;
+          }
+          ++h.njap;  // (updp = 1 and nu = 20 > 16: lm_core.c:578-588 takes the fresh Jacobian)
+          h.nfev += c.o.forward ? M : 2 * M;
+          h.nu = 2;
+          h.updjac = 0;
+          h.updp = 0;
+          h.newjac = 1;
+          if (MULTI) h.chain = 0;
+          ph = D_AFTER_JAC;
+        }
         break;
       } LM_PHASE_END
 
@@ -831,6 +867,7 @@ struct BcMachine {
     int has_lb, has_ub, has_dscl;
     Real lb[M], ub[M], dscl[M];
     int infeasible_mask, bad_input;
+    int bad_config;    // configure(): 0, or the argument check that failed (becomes bad_input of every fit begun)
     int analytic_jac;  // 1: dlevmar_bc_der (caller's Jacobian): no nfev correction at the end (lmbc_core.c:1119-1124)
     int multi;         // candidates evaluated per pass in the projected-gradient search (1 = one at a time).  The
                        // search of lmbc_core.c:885-935 tries t, 0.9t, 0.81t, ... along one fixed direction: the
@@ -945,12 +982,13 @@ struct BcMachine {
     h.spec_state = 1;
   }
 
-  LM_HD void start(const Real *p0, int n_, const Real *lb_, const Real *ub_, const Real *dscl_,
-                   int itmax_, const Real *opts, int want_covar_, int multi_ = 1, int spec_jac_ = 0) {
-    Request<M, Real> &req = h.req;
-    Cool &cool = h.cool;
+  // start() = configure() + begin().  configure() fills the part of Cold every fit of a batch shares (options, box, limits,
+  // flags; the reference's argument checks, which read nothing else); begin() is the per-fit part.  Where 64 machines step
+  // side by side in the lanes of one wave (lane_fit.hip) the kernel configures ONCE, in wave-uniform control flow, so that
+  // the shared half stays in scalar registers, and begins a fit per lane.
+  LM_HD void configure(int n_, const Real *lb_, const Real *ub_, const Real *dscl_, int itmax_, const Real *opts,
+                       int want_covar_, int multi_ = 1, int spec_jac_ = 0) {
     c.multi = (multi_ < 1) ? 1 : ((multi_ > kMaxCand) ? kMaxCand : multi_);
-    h.pg_n = h.pg_single = 0;
     c.o = make_options(opts);
     if (opts) {  // bc_dif reads delta as |opts[4]| and the sign as the FD flavour: lmbc_core.c:1105,1115
       c.o.forward = (opts[4] >= Real(0.0));
@@ -964,6 +1002,33 @@ struct BcMachine {
     c.has_dscl = dscl_ != nullptr;
     c.analytic_jac = 0;
     c.spec_jac = (spec_jac_ && !c.has_dscl) ? 1 : 0;
+    for (int i = 0; i < M; ++i) {
+      c.lb[i] = c.has_lb ? lb_[i] : -LmLimits<Real>::max();
+      c.ub[i] = c.has_ub ? ub_[i] : LmLimits<Real>::max();
+      c.dscl[i] = c.has_dscl ? dscl_[i] : Real(1.0);
+    }
+    c.bad_config = 0;
+    if (c.n < M) {  // lmbc_core.c:440-443
+      c.bad_config = 1;
+      return;
+    }
+    if (c.has_lb && c.has_ub)  // lmbc_core.c:451-454 (box_check, misc_core.c:661-671)
+      for (int i = 0; i < M; ++i)
+        if (c.lb[i] > c.ub[i]) {
+          c.bad_config = 2;
+          return;
+        }
+    if (c.has_dscl)  // lmbc_core.c:456-461
+      for (int i = M; i-- > 0;)
+        if (c.dscl[i] <= Real(0.0)) {
+          c.bad_config = 3;
+          return;
+        }
+  }
+  LM_HD void begin(const Real *p0) {
+    Request<M, Real> &req = h.req;
+    Cool &cool = h.cool;
+    h.pg_n = h.pg_single = 0;
     h.spec_state = 0;
     h.k = 0;
     h.stop = 0;
@@ -971,7 +1036,7 @@ struct BcMachine {
     h.nfev = h.njev = h.nlss = 0;
     h.gprev = 0;
     c.infeasible_mask = 0;
-    c.bad_input = 0;
+    c.bad_input = c.bad_config;
     h.mu = h.jte_inf = h.p_l2 = h.t = cool.t0 = h.gdp = Real(0.0);
     h.p_e2 = cool.init_e2 = h.pdp_e2 = cool.keep_max = Real(0.0);
     h.dp_l2 = LmLimits<Real>::max();
@@ -981,9 +1046,6 @@ struct BcMachine {
     c.ret = kLmError;
     for (int i = 0; i < M; ++i) {
       h.p[i] = p0[i];
-      c.lb[i] = c.has_lb ? lb_[i] : -LmLimits<Real>::max();
-      c.ub[i] = c.has_ub ? ub_[i] : LmLimits<Real>::max();
-      c.dscl[i] = c.has_dscl ? dscl_[i] : Real(1.0);
       h.jte[i] = cool.diag[i] = h.dp[i] = h.pdp[i] = Real(0.0);
     }
     for (int i = 0; i < M * M; ++i) h.jtj[i] = c.covar[i] = Real(0.0);
@@ -991,22 +1053,7 @@ struct BcMachine {
     for (int i = 0; i < kInfoSz; ++i) c.info[i] = Real(0.0);
     clear_req(h, req);
     h.phase = B_DONE;
-    if (c.n < M) {  // lmbc_core.c:440-443
-      c.bad_input = 1;
-      return;
-    }
-    if (c.has_lb && c.has_ub)  // lmbc_core.c:451-454 (box_check, misc_core.c:661-671)
-      for (int i = 0; i < M; ++i)
-        if (c.lb[i] > c.ub[i]) {
-          c.bad_input = 2;
-          return;
-        }
-    if (c.has_dscl)  // lmbc_core.c:456-461
-      for (int i = M; i-- > 0;)
-        if (c.dscl[i] <= Real(0.0)) {
-          c.bad_input = 3;
-          return;
-        }
+    if (c.bad_input) return;
     for (int i = 0; i < M; ++i) c.p_start[i] = h.p[i];
     project(c, h.p);  // lmbc_core.c:514-520; the stderr warning is printed by the host shim from the mask
     for (int i = 0; i < M; ++i)
@@ -1019,6 +1066,11 @@ struct BcMachine {
       h.nfev = 0;
     }
     h.phase = B_INIT_EVAL;
+  }
+  LM_HD void start(const Real *p0, int n_, const Real *lb_, const Real *ub_, const Real *dscl_,
+                   int itmax_, const Real *opts, int want_covar_, int multi_ = 1, int spec_jac_ = 0) {
+    configure(n_, lb_, ub_, dscl_, itmax_, opts, want_covar_, multi_, spec_jac_);
+    begin(p0);
   }
   // (the analytic-Jacobian flag is set by the callers after start(): the kind of the FIRST request does not depend on it)
 
