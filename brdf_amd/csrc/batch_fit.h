@@ -37,7 +37,6 @@ struct BatchCtx {
   int lane_quorum, lane_maxwait;  // lane_fit.hip: lanes waiting for / rounds between two heavy rounds
   int analytic;  // RQ_JAC rows from the model's analytic Jacobian (dlevmar_bc_der / dlevmar_der) instead of finite differences
   int chain;     // dlevmar_dif: trial points per sweep in a chain of rejections (eight-wave kernel; 1 = one at a time)
-  int fuse_init; // dlevmar_dif, eight-wave kernel: f(p0) and the first Jacobian in one sweep (DifMachine::Cold::fuse_init)
   int spec_jac;  // dlevmar_bc_dif: candidates evaluated by Jacobian passes (off in the batched kernels: they are bound by arithmetic)
   double opts[5], lb[kM], ub[kM];
 };

@@ -731,7 +731,6 @@ int batch_fit_launches(const BatchFitArgs &a, const Geometry &g, int *flags, int
   if (g.threads == 512 && (big_path_enabled() || method == 2 || c.analytic)) {  // 1024 < n <= 4096: eight waves per fit (resident_fit.hip)
     c.multi = pg_candidates();
     c.chain = batch_dif_chain();
-    c.fuse_init = dif_fuse_init_enabled() ? 1 : 0;
     if (!fast) HIP_OK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(flags), kNeedsExact, (size_t)a.S, a.stream));
     return resident_batch_enqueue(a.model, method, fast, c, a.stream);
   }

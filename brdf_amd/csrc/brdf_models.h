@@ -224,7 +224,7 @@ struct PassUniforms {
     for (int j = 0; j < kM; ++j) dp[j] = r.dp[j];
     if (r.kind == RQ_JAC && analytic_jac) {
       Mdl::an_scalars(r.p, an);
-    } else if (r.kind == RQ_JAC || r.kind == RQ_DIF_JAC || r.kind == RQ_DIF_INIT_JAC) {
+    } else if (r.kind == RQ_JAC || r.kind == RQ_DIF_JAC) {
       for (int j = 0; j < kM; ++j) {
         double pp[kM] = {r.p[0], r.p[1], r.p[2]};
         pp[j] = r.p[j] + r.d[j];  // "p[j]+=d", misc_core.c:161 / "tmp+d", :202

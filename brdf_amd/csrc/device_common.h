@@ -206,7 +206,6 @@ __host__ __device__ __forceinline__ int slots_of(int kind) {
   case RQ_SCALED:
   case RQ_DIF_INIT: return 1;
   case RQ_JAC: return SumLayout<kM>::JAC;
-  case RQ_DIF_INIT_JAC: return SumLayout<kM>::DIF_INIT_JAC;
   case RQ_DIF_JAC:
   case RQ_DIF_UPDATE: return SumLayout<kM>::DIF_JAC;
   case RQ_DIF_TRIAL: return SumLayout<kM>::DIF_TRIAL;

@@ -73,10 +73,8 @@ enum ReqKind : int {
                      //   aux (step accepted) else x-hx; finally hx <- wrk if aux
   RQ_EVAL_MULTI = 8, // sums[j] = sum (x-f(pk[j]))^2 for j < nk: several candidates of a projected-gradient search
                      //   in ONE sweep (the samples are read once; a pass's fixed cost is paid once)
-  RQ_YIELD = 9,      // no pass: a GATED step (BcMachine::run) stopped in front of an expensive phase; call step() again
+  RQ_YIELD = 9       // no pass: a GATED step (BcMachine::run) stopped in front of an expensive phase; call step() again
                      //   with heavy = true (lane_fit.hip runs the expensive phases of its 64 machines in common rounds)
-  RQ_DIF_INIT_JAC = 10  // RQ_DIF_INIT and the RQ_DIF_JAC of the first iteration in ONE sweep (DifMachine::Cold::fuse_init):
-                     //   hx[sel_hx] <- f(p); J[sel_j] <- FD Jacobian at p; sums = [JtJ lower, Jte, sum e^2]
 };
 
 constexpr int kMaxCand = 8;  // candidates per RQ_EVAL_MULTI
@@ -120,7 +118,6 @@ struct SumLayout {
   static constexpr int NL = M * (M + 1) / 2;
   static constexpr int JAC = NL + M + 1;          // RQ_JAC
   static constexpr int DIF_JAC = NL + M;          // RQ_DIF_JAC
-  static constexpr int DIF_INIT_JAC = NL + M + 1; // RQ_DIF_INIT_JAC
   static constexpr int DIF_TRIAL = 1 + NL + 2 * M;  // RQ_DIF_TRIAL
   static constexpr int MAX = DIF_TRIAL > JAC ? DIF_TRIAL : JAC;
 };
@@ -356,11 +353,6 @@ struct DifMachine {
                       //   most of the passes.  RQ_EVAL_MULTI evaluates them in one sweep; they are judged in the reference's order,
                       //   only the judged ones are counted, and a candidate that reduces the error is evaluated again by the plain
                       //   trial pass (which forms the Broyden sums): p, info[] and the trajectory are those of one trial at a time.
-    int fuse_init;    // 1: the first pass is RQ_DIF_INIT_JAC -- f(p0) and the finite-difference Jacobian the first iteration opens
-                      //   with (lm_core.c:551-564, then :578-588 at the same point: nu = 20 > 16 forces it) in one sweep.  The
-                      //   evaluation's sum of squares comes out of the Jacobian sweep bit for bit (same residuals, same order).
-                      //   If the fit stops in front of its first iteration (itmax = 0, ||e||^2 <= eps3, a non-finite start)
-                      //   the Jacobian is discarded and never counted: info[] and p are those of the two-pass start.
     Real info[kInfoSz], covar[M * M];
     int ret;
   };
@@ -406,13 +398,11 @@ struct DifMachine {
   Cold c;
   Hot h;
 
-  LM_HD void start(const Real *p0, int n_, int itmax_, const Real *opts, int want_covar_, int speculative_ = 1, int multi_ = 1,
-                   int fuse_init_ = 0) {
+  LM_HD void start(const Real *p0, int n_, int itmax_, const Real *opts, int want_covar_, int speculative_ = 1, int multi_ = 1) {
     Request<M, Real> &req = h.req;
     Cool &cool = h.cool;
     c.o = make_options(opts);
     c.speculative = speculative_;
-    c.fuse_init = (fuse_init_ && speculative_) ? 1 : 0;
     c.multi = (multi_ < 1 || !speculative_) ? 1 : ((multi_ > kMaxCand) ? kMaxCand : multi_);
     h.chain = h.single = h.mcnt = 0;
     for (int j = 0; j < kMaxCand; ++j) cool.ml2[j] = Real(0.0);
@@ -447,11 +437,6 @@ struct DifMachine {
     }
     req.kind = RQ_DIF_INIT;
     for (int i = 0; i < M; ++i) req.p[i] = h.p[i];
-    if (c.fuse_init) {
-      req.kind = RQ_DIF_INIT_JAC;
-      req.central = !c.o.forward;
-      fd_steps<M>(h.p, c.o.delta, req.d);
-    }
     h.phase = D_INIT_EVAL;
   }
 
@@ -495,30 +480,11 @@ struct DifMachine {
       }
       LM_PHASE(D_INIT_EVAL) {  // lm_core.c:551-564
         h.nfev = 1;
-        h.p_e2 = c.fuse_init ? s[SumLayout<M>::DIF_INIT_JAC - 1] : s[0];
+        h.p_e2 = s[0];
         cool.init_e2 = h.p_e2;
         if (!lm_finite(h.p_e2)) h.stop = 7;
         h.nu = 20;
         ph = D_ITER_TOP;
-        if (c.fuse_init) {  // the top of iteration 0 (D_ITER_TOP below), whose Jacobian pass this sweep already was
-          if (!(h.k < c.itmax && !h.stop)) {
-            ph = D_FINISH;
-            break;
-          }
-          if (h.p_e2 <= c.o.eps3) {
-            h.stop = 6;
-            ph = D_FINISH;
-            break;
-          }
-          ++h.njap;  // (updp = 1 and nu = 20 > 16: lm_core.c:578-588 takes the fresh Jacobian)
-          h.nfev += c.o.forward ? M : 2 * M;
-          h.nu = 2;
-          h.updjac = 0;
-          h.updp = 0;
-          h.newjac = 1;
-          if (MULTI) h.chain = 0;
-          ph = D_AFTER_JAC;
-        }
         break;
       } LM_PHASE_END
 

@@ -92,7 +92,6 @@ struct ResidentCtx {
   double p0[kM], opts[5], lb[kM], ub[kM], dscl[kM];
   int itmax, has_opts, has_lb, has_ub, has_dscl, want_covar, multi, analytic;
   int chain;     // dlevmar_dif: trial points per sweep in a chain of rejections (DifMachine::Cold::multi)
-  int fuse_init; // dlevmar_dif: f(p0) and the first iteration's Jacobian in one sweep (DifMachine::Cold::fuse_init)
   int spec_jac;  // dlevmar_bc_dif / bc_der: candidates evaluated by Jacobian passes (BcMachine::Cold::spec_jac)
   Mailbox *mbox;
   int n;
@@ -617,26 +616,18 @@ __device__ __forceinline__ void sweep_pass(int kind, const PassUniforms<MODEL> &
     }
     break;
   case RQ_DIF_JAC:
-  case RQ_DIF_INIT_JAC:  // ... and RQ_DIF_INIT in the same sweep (DifMachine::Cold::fuse_init): the row's base value f(p) is the
-                         // evaluation's (same shape(), same combine()), stored as hx; its square joins the sums in slot order
     if constexpr (METHOD == 0) {
-      const bool init = kind == RQ_DIF_INIT_JAC;  // (wave-uniform)
       for_samples<U>(nk, [&](int k) {
         const int s = k * kRThreads + tid;
-        double h = init ? 0.0 : st.get(kFhx, k);
+        const double h = st.get(kFhx, k);
         double f0 = 0.0, j[kM];
-        model_fd_row<MODEL, FAST>(u, st.get(kFc0, k), prep(k), init, f0, h, !init, j);
-        if (init) {
-          h = f0;
-          st.set(kFhx, k, h);
-        }
+        model_fd_row<MODEL, FAST>(u, st.get(kFc0, k), prep(k), false, f0, h, true, j);
         double e = st.get(kFx, k) - h;
         if (dead(k)) e = j[0] = j[1] = j[2] = 0.0;
         jl[s] = j[0];
         jl[kRCap + s] = j[1];
         jl[2 * kRCap + s] = j[2];
         acc_normal_eq_fma(j, e, acc, acc + kNL);
-        acc[kNL + kM] = fma(e, e, acc[kNL + kM]);  // (read by RQ_DIF_INIT_JAC only)
       });
     }
     break;
@@ -728,7 +719,6 @@ __device__ __forceinline__ void reduce_pass(int kind, const double *acc, double 
   if constexpr (METHOD == 0) {
     switch (kind) {
     case RQ_DIF_JAC: worker_reduce<SumLayout<kM>::DIF_JAC, false>(acc, mx, red, sums, st_, last_); break;
-    case RQ_DIF_INIT_JAC: worker_reduce<SumLayout<kM>::DIF_INIT_JAC, false>(acc, mx, red, sums, st_, last_); break;
     case RQ_DIF_TRIAL: worker_reduce<kTrialSums, false>(acc, mx, red, sums, st_, last_); break;
     case RQ_EVAL_MULTI: worker_reduce<kMaxCand, false>(acc, mx, red, sums, st_, last_); break;
     default: worker_reduce<1, false>(acc, mx, red, sums, st_, last_); break;
@@ -789,7 +779,7 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
     // (the arguments are copied into locals first: handing start() pointers INTO the by-value argument structs makes hipcc
     // spill the whole struct to scratch and serve every later ctx.field access from there -- measured +1.3 us per pass)
     double p0[kM], opts[5], lb[kM], ub[kM], dscl[kM];
-    int itmax, has_opts, has_lb, has_ub, has_dscl = 0, want_covar = 0, multi, analytic, chain, spec_jac, fuse_init;
+    int itmax, has_opts, has_lb, has_ub, has_dscl = 0, want_covar = 0, multi, analytic, chain, spec_jac;
     if constexpr (BATCHED) {
 #pragma unroll
       for (int i = 0; i < kM; ++i) {
@@ -801,7 +791,7 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
 #pragma unroll
       for (int i = 0; i < 5; ++i) opts[i] = bctx.opts[i];
       itmax = bctx.itmax, has_opts = bctx.has_opts, has_lb = bctx.has_lb, has_ub = bctx.has_ub, multi = bctx.multi, analytic = bctx.analytic;
-      chain = bctx.chain, spec_jac = bctx.spec_jac, fuse_init = bctx.fuse_init;
+      chain = bctx.chain, spec_jac = bctx.spec_jac;
     } else {
 #pragma unroll
       for (int i = 0; i < kM; ++i) {
@@ -813,18 +803,18 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
 #pragma unroll
       for (int i = 0; i < 5; ++i) opts[i] = ctx.opts[i];
       itmax = ctx.itmax, has_opts = ctx.has_opts, has_lb = ctx.has_lb, has_ub = ctx.has_ub, has_dscl = ctx.has_dscl;
-      want_covar = ctx.want_covar, multi = ctx.multi, analytic = ctx.analytic, chain = ctx.chain, spec_jac = ctx.spec_jac, fuse_init = ctx.fuse_init;
+      want_covar = ctx.want_covar, multi = ctx.multi, analytic = ctx.analytic, chain = ctx.chain, spec_jac = ctx.spec_jac;
     }
     const double *po = has_opts ? opts : nullptr;
     if constexpr (METHOD == 0) {
-      sm.start(p0, n, itmax, po, want_covar, /*speculative=*/1, chain, fuse_init);
+      sm.start(p0, n, itmax, po, want_covar, /*speculative=*/1, chain);
     } else if constexpr (METHOD == 1) {
       sm.start(p0, n, has_lb ? lb : nullptr, has_ub ? ub : nullptr, has_dscl ? dscl : nullptr, itmax, po, want_covar, multi, BATCHED ? 0 : spec_jac);
       sm.c.analytic_jac = analytic;
     } else {
       sm.start(p0, n, itmax, po, want_covar);
     }
-    (void)analytic, (void)chain, (void)spec_jac, (void)fuse_init;
+    (void)analytic, (void)chain, (void)spec_jac;
   }
   if (tid == 0) s_abort = s_bad = 0;
   if (tid <= kM) dp_prev[tid] = 0.0;
@@ -924,7 +914,7 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
     for (;; ++epoch) {
       const int kind = sm.h.req.kind;
       if (kind == RQ_DONE) break;
-      if (kind == RQ_JAC || kind == RQ_DIF_JAC || kind == RQ_DIF_INIT_JAC) ++n_jac;
+      if (kind == RQ_JAC || kind == RQ_DIF_JAC) ++n_jac;
       RTRACE(ctx, epoch, 0, wall_clock64());
       {
         bool pend;
@@ -984,7 +974,6 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
         if constexpr (METHOD == 0) {
           switch (kind) {
           case RQ_DIF_JAC: alive = control_exchange<SumLayout<kM>::DIF_JAC, false>(ctx, epoch, sums, &s_abort, st_, last_); break;
-          case RQ_DIF_INIT_JAC: alive = control_exchange<SumLayout<kM>::DIF_INIT_JAC, false>(ctx, epoch, sums, &s_abort, st_, last_); break;
           case RQ_DIF_TRIAL: alive = control_exchange<kTrialSums, false>(ctx, epoch, sums, &s_abort, st_, last_); break;
           case RQ_EVAL_MULTI: alive = control_exchange<kMaxCand, false>(ctx, epoch, sums, &s_abort, st_, last_); break;
           default: alive = control_exchange<1, false>(ctx, epoch, sums, &s_abort, st_, last_); break;
@@ -1228,7 +1217,6 @@ int resident_attempt(const StreamFitArgs &a, RWorkspace &ws, bool *retry_exact, 
   c.want_covar = a.covar != nullptr;
   c.multi = pg_candidates();
   c.chain = dif_chain_candidates();
-  c.fuse_init = dif_fuse_init_enabled() ? 1 : 0;
   c.spec_jac = bc_spec_jac_enabled() ? 1 : 0;
   c.analytic = a.analytic ? 1 : 0;
   c.mbox = ws.d_mbox;

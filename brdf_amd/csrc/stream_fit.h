@@ -111,7 +111,6 @@ int capture_fit_run(int model, const unsigned char *d_images, int L, int H, int 
 
 bool brdf_fast_path_enabled();  // false when BRDF_HIP_EXACT_POW=1
 int pg_candidates();            // BRDF_HIP_PG_MULTI (default kMaxCand)
-bool dif_fuse_init_enabled();  // BRDF_HIP_DIF_FUSE_INIT (default on): the resident dlevmar_dif kernels start with RQ_DIF_INIT_JAC
 int dif_chain_candidates();     // BRDF_HIP_DIF_CHAIN (default kMaxCand): dlevmar_dif trial points per sweep in a chain of rejections
 bool bc_spec_jac_enabled();     // BRDF_HIP_SPEC_JAC (default on): single fits evaluate dlevmar_bc_dif candidates by Jacobian passes
 void set_error(const char *fmt, ...);

@@ -686,10 +686,6 @@ int pg_candidates() {
 
 // BRDF_HIP_DIF_CHAIN=k: dlevmar_dif trial points per sweep in a chain of rejections (lm_machine.h: DifMachine::Cold::multi;
 // default 8, 1 = one at a time)
-bool dif_fuse_init_enabled() {
-  const char *e = getenv("BRDF_HIP_DIF_FUSE_INIT");
-  return !(e && e[0] == '0');
-}
 int dif_chain_candidates() {
   const char *e = getenv("BRDF_HIP_DIF_CHAIN");
   const int k = e ? atoi(e) : kMaxCand;

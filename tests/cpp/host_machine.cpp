@@ -20,7 +20,6 @@ namespace {
 int g_speculative = 1;  // dif protocol under test (see lm_machine.h)
 int g_multi = 1;        // bc: candidates per projected-gradient sweep
 int g_dif_multi = 1;    // dif: trial points per sweep in a chain of rejections (DifMachine::Cold::multi)
-int g_dif_fuse_init = 0;  // dif: f(p0) and the first Jacobian in one pass (DifMachine::Cold::fuse_init)
 int g_spec_jac = 0;     // bc: candidates evaluated by Jacobian passes (BcMachine::Cold::spec_jac)
 
 template <int MODEL, bool FAST>
@@ -99,21 +98,6 @@ struct HostPasses {
       s[0] = orc_l2_residual(e.data(), x, h.data(), n);
       break;
     }
-    case RQ_DIF_INIT_JAC: {  // RQ_DIF_INIT, then RQ_DIF_JAC, on the same request
-      std::vector<double> &h = hx[r.sel_hx];
-      std::vector<double> &Jc = J[r.sel_j];
-      for (int i = 0; i < n; ++i) h[i] = model_value<MODEL, FAST>(u, c0[i], prep(i));
-      s[SumLayout<3>::DIF_INIT_JAC - 1] = orc_l2_residual(e.data(), x, h.data(), n);
-      for (int i = 0; i < n; ++i) {
-        double f0 = 0.0;
-        model_fd_row<MODEL, FAST>(u, c0[i], prep(i), false, f0, h[i], true, &Jc[3 * i]);
-        e[i] = x[i] - h[i];
-      }
-      orc_jtj_jte(Jc.data(), e.data(), jtj, jte, n, 3, 0);
-      pack_lower(jtj, s);
-      for (int i = 0; i < 3; ++i) s[SumLayout<3>::NL + i] = jte[i];
-      break;
-    }
     case RQ_DIF_JAC: {
       std::vector<double> &h = hx[r.sel_hx];
       std::vector<double> &Jc = J[r.sel_j];
@@ -182,7 +166,7 @@ int fit(int method, double *angles, double *x, int n, double *p, int itmax, doub
     HostPasses<MODEL, FAST> hp(angles, x, n, 0);
     hp.speculative = g_speculative;
     DifMachine<3> m;
-    m.start(p, n, itmax, opts, covar != nullptr, g_speculative, g_dif_multi, g_dif_fuse_init);
+    m.start(p, n, itmax, opts, covar != nullptr, g_speculative, g_dif_multi);
     while (m.h.req.kind != RQ_DONE) {
       hp.run(m.h.req, s, mx);
       ++np;
@@ -255,5 +239,4 @@ extern "C" int hm_brdf_fit_fast(int method, int model, double *angles, double *x
 extern "C" void hm_set_dif_protocol(int speculative) { g_speculative = speculative; }
 extern "C" void hm_set_bc_multi(int k) { g_multi = k; }
 extern "C" void hm_set_dif_multi(int k) { g_dif_multi = k; }
-extern "C" void hm_set_dif_fuse_init(int on) { g_dif_fuse_init = on; }
 extern "C" void hm_set_bc_spec_jac(int on) { g_spec_jac = on; }

@@ -262,8 +262,8 @@ def test_full_size_properties(gpu, method, model):
 @pytest.mark.parametrize("model,n", [(2, 1_000_000), (1, 1_000_000), (2, 100003), (0, 5000), (1, 300)])
 def test_shared_sweeps_do_not_change_a_bit(gpu, monkeypatch, model, n):
     """Fewer sweeps, same arithmetic.  dlevmar_dif evaluates the trial points of a chain of rejections up to eight to a sweep
-    (BRDF_HIP_DIF_CHAIN) and, in the resident regime, f(p0) together with the first Jacobian (BRDF_HIP_DIF_FUSE_INIT);
-    dlevmar_bc_dif / bc_der evaluate a candidate by the Jacobian pass the next iteration would open with (BRDF_HIP_SPEC_JAC).  Every sum that is judged is formed by the same per-lane order and the same trees as in the plain
+    (BRDF_HIP_DIF_CHAIN); dlevmar_bc_dif / bc_der evaluate a candidate by the Jacobian pass the next iteration would open with
+    (BRDF_HIP_SPEC_JAC).  Every sum that is judged is formed by the same per-lane order and the same trees as in the plain
     passes, so p, info[] (iterations, nfev, njev, nlss) and the covariance must be bit-identical with and without them --
     in the resident regime and in the launch chain."""
     torch, brdf_amd, dev = gpu
@@ -277,7 +277,6 @@ def test_shared_sweeps_do_not_change_a_bit(gpu, monkeypatch, model, n):
             for on in ("8", "1"):
                 monkeypatch.setenv("BRDF_HIP_DIF_CHAIN", on)
                 monkeypatch.setenv("BRDF_HIP_SPEC_JAC", "1" if on == "8" else "0")
-                monkeypatch.setenv("BRDF_HIP_DIF_FUSE_INIT", "1" if on == "8" else "0")
                 r = _dev_fit(gpu, method, model, angles, x, lb=lb, ub=ub, want_covar=True)
                 got.append((r, brdf_amd.last_fit_stats()["passes"]))
             (a, pa), (b, pb) = got

@@ -225,48 +225,6 @@ def test_rejection_chains_evaluated_together_are_bit_exact(k):
         L.hm.hm_set_dif_multi(1)
 
 
-def test_first_pass_with_its_jacobian_is_bit_exact():
-    """dlevmar_dif, DifMachine::Cold::fuse_init: f(p0) and the finite-difference Jacobian of the first iteration in ONE pass
-    (RQ_DIF_INIT_JAC).  p and info[] are the reference's for every fixture and for ragged random fits, in exactly one pass
-    less; a fit that ends in front of its first iteration (itmax = 0, ||e||^2 <= eps3, a non-finite start) discards the
-    Jacobian uncounted: nfev = 1, njev = 0, as the reference reports them."""
-    try:
-        for f in FITS:
-            if f["method"] != 0:
-                continue
-            angles, x, _ = synth.make_single(f["model"], f["n"])
-            args = (0, f["model"], angles, x, synth.P0[f["model"]], synth.ITMAX, synth.OPTS, synth.LB, synth.UB)
-            L.hm.hm_set_dif_fuse_init(0)
-            _, _, _, base = _hm_passes(*args)
-            L.hm.hm_set_dif_fuse_init(1)
-            r, p, info, passes = _hm_passes(*args)
-            assert r == f["ret"] and np.array_equal(p, _hex(f["p"])) and np.array_equal(info, _hex(f["info"]))
-            assert passes == base - 1
-        L.hm.hm_set_dif_multi(8)  # ... and together with the rejection chains, as the resident kernels run
-        for seed in (1, 2, 3, 4, 5, 6):
-            for n in (3, 5, 17, 100, 257):
-                model = seed % 3
-                angles, x, _ = synth.make_surfels(model, n, first=seed * 1000, count=1, seed=synth.SEED + seed)
-                for opts in (synth.OPTS, None, [1e-3, 1e-17, 1e-17, 1e-17, -1e-6]):
-                    a = L.brdf_fit("orc", 0, model, angles[0], x[0], synth.P0[model], 60, opts, synth.LB, synth.UB)
-                    b = L.brdf_fit("hm", 0, model, angles[0], x[0], synth.P0[model], 60, opts, synth.LB, synth.UB)
-                    assert a[0] == b[0] and np.array_equal(a[1], b[1], equal_nan=True) and np.array_equal(a[2], b[2], equal_nan=True)
-        angles, x, _ = synth.make_single(1, 200)
-        early = [dict(itmax=0, opts=synth.OPTS, x=x),                               # the loop never runs
-                 dict(itmax=50, opts=[1e-3, 1e-17, 1e-17, 1e30, 1e-6], x=x),        # ||e||^2 <= eps3 at the start: stop 6
-                 dict(itmax=50, opts=synth.OPTS, x=np.where(np.arange(200) == 7, np.nan, x))]  # non-finite start: stop 7
-        for case in early:
-            a = L.brdf_fit("orc", 0, 1, angles, case["x"], synth.P0[1], case["itmax"], case["opts"], synth.LB, synth.UB)
-            b = L.brdf_fit("hm", 0, 1, angles, case["x"], synth.P0[1], case["itmax"], case["opts"], synth.LB, synth.UB)
-            keep = np.arange(10) != 4  # (info[4] = mu / max diag(J^T J) of a Jacobian that was never formed: the reference reads
-            #                            uninitialised memory there, lm_core.c:809-823)
-            assert a[0] == b[0] and np.array_equal(a[1], b[1], equal_nan=True) and np.array_equal(a[2][keep], b[2][keep], equal_nan=True)
-            assert b[2][7] == 1 and b[2][8] == 0
-    finally:
-        L.hm.hm_set_dif_fuse_init(0)
-        L.hm.hm_set_dif_multi(1)
-
-
 @pytest.mark.parametrize("pg", [1, 8])
 def test_candidates_evaluated_by_jacobian_passes_are_bit_exact(pg):
     """dlevmar_bc_dif / dlevmar_bc_der, BcMachine::Cold::spec_jac: the LM trial point, every line-search point and the
