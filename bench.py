@@ -459,6 +459,7 @@ def single_line(args, model, ctx, steps, warmup, angles, x, rank0_cpu):
     torch, dist, rank, world, backend, dev, stub = ctx
     p0, opts, lb, ub, itmax = synth.P0[model], synth.OPTS, synth.LB, synth.UB, synth.ITMAX
     import brdf_amd
+    brdf_amd.set_launch_timing(True)  # (the roofline's kernel duration: an event pair around every resident launch)
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
     # each rank owns one material: same generator, different seed -> different planes and noise
     a_dev = torch.from_numpy(angles).to(dev)
@@ -469,7 +470,8 @@ def single_line(args, model, ctx, steps, warmup, angles, x, rank0_cpu):
             brdf_amd.fit_single(method, model, a_dev, x_dev, p0, lb=lb, ub=ub, itmax=itmax, opts=opts)
         res_np = np.zeros((steps, 13))  # filled inside the timed loop (numpy: ~1 us per row; torch CPU indexing costs ~20 us)
         passes = jac = launches = 0
-        dev_us = 0.0
+        dev_us = kern_us = 0.0
+        kern_n = 0
         if world > 1 or FORCE_COLL:
             dist.barrier()
         torch.cuda.synchronize()
@@ -491,6 +493,9 @@ def single_line(args, model, ctx, steps, warmup, angles, x, rank0_cpu):
             launches += st["launches"]
             jac += st["jac_passes"]
             dev_us += st["device_us"]
+            if st["kernel_us"] >= 0.0:  # resident regime: the event pair the library recorded around this fit's launch
+                kern_us += st["kernel_us"]
+                kern_n += 1
         ev1.record()
         results = torch.from_numpy(res_np)
         gathered = None
@@ -504,7 +509,7 @@ def single_line(args, model, ctx, steps, warmup, angles, x, rank0_cpu):
         ev_ms = ev0.elapsed_time(ev1)
         fit_ms = sum(a.elapsed_time(b) for a, b in evs)
         stat = torch.tensor([wall, float(results[:, 10].sum().item()) * N_SAMPLES, ev_ms, float(passes), float(jac), dev_us,
-                             float(launches), fit_ms],
+                             float(launches), fit_ms, kern_us, float(kern_n)],
                             dtype=torch.float64, device=coll_dev)
         if world > 1 or FORCE_COLL:
             allstat = [torch.empty_like(stat) for _ in range(world)]
@@ -538,7 +543,15 @@ def single_line(args, model, ctx, steps, warmup, angles, x, rank0_cpu):
             # pass kernel in them (launch chain: the passes plus the few run-ahead launches per fit that find it finished):
             # the population rocprofv3 averages over.  region_us_per_launch = the whole timed region / launches, i.e.
             # with the host's gaps between two fits
-            "avg_launch_us": 1e3 * float(allstat[0, 7]) / max(1.0, float(allstat[0, 6])),
+            # Resident regime (one launch per fit): avg_launch_us = the HIP event pair the LIBRARY records on the launch stream
+            # right in front of and right behind the kernel launch (brdf_hip_set_launch_timing) -- the kernel's duration, what
+            # rocprofv3 --kernel-trace reports for it; call_us_per_launch = the pair recorded here around the whole synchronous
+            # call (the kernel plus the host's launch and completion latency, 10-20 us)
+            "avg_launch_us": (float(allstat[0, 8]) / float(allstat[0, 9])) if float(allstat[0, 9]) == float(allstat[0, 6]) and float(allstat[0, 9]) > 0
+                             else 1e3 * float(allstat[0, 7]) / max(1.0, float(allstat[0, 6])),
+            "launch_timer": "library event pair around the kernel launch" if float(allstat[0, 9]) == float(allstat[0, 6]) and float(allstat[0, 9]) > 0
+                            else "event pair around the call",
+            "call_us_per_launch": 1e3 * float(allstat[0, 7]) / max(1.0, float(allstat[0, 6])),
             "region_us_per_launch": 1e3 * float(allstat[0, 2]) / max(1.0, float(allstat[0, 6])),
             "launches_per_step": float(allstat[0, 6]) / steps,
             # device clock (s_memrealtime) from the first to the finishing pass / passes: sweeping launches only
@@ -570,7 +583,8 @@ def single_line(args, model, ctx, steps, warmup, angles, x, rank0_cpu):
              "traffic": traffic, "traffic_source": traffic_src, "kernel": "brdf::" + kernel, "regime": "resident" if resident else "launch chain",
              "algorithmic_bytes_per_launch": bytes_per_launch, "reference_passes_per_launch": ref_per_launch,
              "sweeps_per_launch": sweeps_per_launch, "achieved_by_executed_sweeps": by_sweeps, "frac_by_executed_sweeps": by_sweeps / HBM_PEAK_GBS,
-             "avg_launch_us": head["avg_launch_us"], "region_us_per_launch": head["region_us_per_launch"],
+             "avg_launch_us": head["avg_launch_us"], "launch_timer": head["launch_timer"], "call_us_per_launch": head["call_us_per_launch"],
+             "region_us_per_launch": head["region_us_per_launch"],
              "avg_sweeping_launch_us": head["avg_sweeping_launch_us"], "launches_per_step": head["launches_per_step"],
              "alu": alu_roofline(kernel, head["evals_per_step_rank0"] / (head["avg_launch_us"] * 1e-6 * max(1.0, head["launches_per_step"])),
                                  evals_per_launch)}
@@ -584,7 +598,7 @@ def single_line(args, model, ctx, steps, warmup, angles, x, rank0_cpu):
         f"achieved = SURVEY.md section 8d's algorithmic bytes ({bpsp} B per sample-pass: "
         f"{'3' if model == 2 else '2'} planes + measurement, fp64) x 1e6 samples x the passes of the reference algorithm for this fit "
         "(reference_passes_per_launch = one per Jacobian + one per other evaluation, from info[7] / info[8]) / the "
-        "average HIP-event time of a fit's launch (one event pair per fit on the launch stream); in the "
+        "average HIP-event time of a fit's launch (launch_timer: in the resident regime the event pair the library records on the launch stream right in front of and right behind the kernel launch, brdf_hip_set_launch_timing; call_us_per_launch = the pair around the whole synchronous call, i.e. with the host's launch and completion latency); in the "
         "resident regime one launch is a whole fit: the in-launch exchanges and serial LM steps are part of it.  The launch makes "
         "sweeps_per_launch sweeps over its resident samples for them (shared sweeps: DESIGN.md section 2); frac_by_executed_sweeps counts "
         "those instead.  region_us_per_launch adds the host's gap between two fits; avg_sweeping_launch_us = device clock per sweep.  "
@@ -606,7 +620,7 @@ def single_line(args, model, ctx, steps, warmup, angles, x, rank0_cpu):
         "roofline": roof,
         "fitted_params": head["p"], "sumsq": head["sumsq"],
         "bc_dif": {k: out["bc_dif"][k] for k in ("value", "ms_per_step", "nfev", "njev", "iters", "reference_passes_per_step", "passes_per_step",
-                                                    "launches_per_step", "avg_launch_us", "avg_sweeping_launch_us", "p")},
+                                                    "launches_per_step", "avg_launch_us", "launch_timer", "call_us_per_launch", "avg_sweeping_launch_us", "p")},
     }
     line["bc_dif"]["roofline"] = {k: v for k, v in roofline_of(out["bc_dif"], 1).items()
                                   if k in ("achieved", "frac", "traffic", "traffic_source", "kernel", "algorithmic_bytes_per_launch", "avg_launch_us",
@@ -646,23 +660,42 @@ def channels_line(args, model, ctx, steps, warmup, angles, x, K=3):
     xd = torch.stack(xs).contiguous()
     kw = dict(lb=lb, ub=ub, itmax=itmax, opts=opts)
 
+    brdf_amd.set_launch_timing(True)
+
     def timed(fn):
+        """(last result, wall, us per step by the library's event pairs around the kernel launches -- by the event pair around
+        the call where a step did not run as resident launches --, us per step by the event pair around the call)"""
         for _ in range(warmup):
             fn()
         torch.cuda.synchronize()
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        kern = []
         t0 = time.perf_counter()
         for s_ in range(steps):
             evs[s_][0].record()
-            r = fn()
+            r, k_us = fn()
             evs[s_][1].record()
+            kern.append(k_us)
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
-        return r, wall, sum(a.elapsed_time(b) for a, b in evs) * 1e3 / steps
+        call_us = sum(a.elapsed_time(b) for a, b in evs) * 1e3 / steps
+        return r, wall, (sum(kern) / steps if min(kern) >= 0.0 else call_us), call_us
 
-    shared, wall_sh, us_sh = timed(lambda: brdf_amd.fit_channels(1, model, a_dev, xd, p0, **kw))
+    def shared_step():
+        r = brdf_amd.fit_channels(1, model, a_dev, xd, p0, **kw)
+        return r, brdf_amd.last_channels_stats(K)["kernel_us"]
+
+    def serial_step():
+        out, us = [], 0.0
+        for c in range(K):
+            out.append(brdf_amd.fit_single(1, model, a_dev, xd[c], p0, **kw))
+            k_us = brdf_amd.last_fit_stats()["kernel_us"]
+            us = us + k_us if (k_us >= 0.0 and us >= 0.0) else -1.0
+        return out, us
+
+    shared, wall_sh, us_sh, call_sh = timed(shared_step)
     st = brdf_amd.last_channels_stats(K)
-    serial, wall_se, us_se = timed(lambda: [brdf_amd.fit_single(1, model, a_dev, xd[c], p0, **kw) for c in range(K)])
+    serial, wall_se, us_se, call_se = timed(serial_step)
     nfev = [float(r.info[7]) for r in shared]
     njev = [float(r.info[8]) for r in shared]
     ref_passes = sum(nj + (nf - 4.0 * nj) for nf, nj in zip(nfev, njev))  # the reference's streaming visits, all channels
@@ -678,8 +711,8 @@ def channels_line(args, model, ctx, steps, warmup, angles, x, K=3):
         "workload": f"{K} channels over one set of planes (one truth, {K} noise draws), {MODEL_NAME[model]}, 1,000,000 samples each, dlevmar_bc_dif, "
                     "brdf_hip_fit_channels_dev: one shared resident launch; one step = the K fits",
         "channels": K, "entry_point": "dlevmar_bc_dif", "steps": steps, "shared_launch": bool(st["shared_launch"]),
-        "value": evals * steps / wall_sh, "unit": "residual-evals/s", "ms_per_step": 1e3 * wall_sh / steps, "launch_us": us_sh,
-        "one_after_the_other": {"ms_per_step": 1e3 * wall_se / steps, "launches_us": us_se, "speedup_of_the_shared_launch": us_se / us_sh},
+        "value": evals * steps / wall_sh, "unit": "residual-evals/s", "ms_per_step": 1e3 * wall_sh / steps, "launch_us": us_sh, "call_us": call_sh,
+        "one_after_the_other": {"ms_per_step": 1e3 * wall_se / steps, "launches_us": us_se, "calls_us": call_se, "speedup_of_the_shared_launch": us_se / us_sh},
         "nfev": nfev, "passes": [c["passes"] for c in st["channels"]], "bit_identical_to_single_fits": bool(identical),
         "fitted_params": [[float(v) for v in r.p] for r in shared],
         "roofline": {"bound": "hbm", "kernel": "brdf::" + kernel, "peak": HBM_PEAK_GBS, "unit": "GB/s",

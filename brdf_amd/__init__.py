@@ -7,4 +7,4 @@ torch.distributed (RCCL) for the surfel-sharded multi-GPU driver, and the synthe
 from . import synth  # noqa: F401
 from ._lib import LIB_PATH, lib, last_error  # noqa: F401
 from .fit import (METHOD_BC_DER, METHOD_BC_DIF, METHOD_DER, METHOD_DIF, MODEL_BLINN_PHONG, MODEL_PHONG, MODEL_WARD, FitResult, fit_batch,  # noqa: F401
-                  cosines, fit_capture, fit_capture_single, fit_channels, fit_single, last_channels_stats, host_dlevmar, last_fit_stats, led_table, model_eval, chkjac, model_jacobian)
+                  cosines, fit_capture, fit_capture_single, fit_channels, fit_single, last_channels_stats, host_dlevmar, last_fit_stats, led_table, model_eval, chkjac, model_jacobian, set_launch_timing)

@@ -71,6 +71,9 @@ ABI = {
     "brdf_hip_device_count": (C.c_int, []),
     "brdf_hip_last_error": (C.c_char_p, []),
     "brdf_hip_last_fit_launches": (C.c_longlong, []),
+    "brdf_hip_set_launch_timing": (None, [C.c_int]),
+    "brdf_hip_last_fit_kernel_us": (C.c_double, []),
+    "brdf_hip_last_channels_kernel_us": (C.c_double, []),
     "brdf_hip_last_fit_stamps": (C.c_int, [C.POINTER(C.c_longlong)]),
     "brdf_hip_last_fit_trace": (C.c_int, [C.POINTER(C.c_longlong), C.c_int]),
     "brdf_hip_last_fit_stats": (C.c_int, [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong),

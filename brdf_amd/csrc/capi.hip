@@ -659,6 +659,10 @@ int brdf_hip_last_fit_stats(long long *passes, long long *jac_passes, long long 
 
 long long brdf_hip_last_fit_launches(void) { return stream_fit_last_stats().launches; }
 
+void brdf_hip_set_launch_timing(int on) { set_launch_timing(on != 0); }
+double brdf_hip_last_fit_kernel_us(void) { return stream_fit_last_stats().kernel_us; }
+double brdf_hip_last_channels_kernel_us(void) { return channels_last_shared() ? channels_last_stats(0).kernel_us : -1.0; }
+
 /* diagnostic builds (-DBRDF_STAMPS) only: one epoch's timeline of every workgroup of the last resident fit */
 int brdf_hip_last_fit_trace(long long *out, int max_rows) { return resident_fit_last_trace(out, max_rows); }
 

@@ -511,6 +511,7 @@ struct CWorkspace {
   unsigned launches = 0;
   FitStats stats[kMaxChannels] = {};
   double launch_us = 0.0;
+  LaunchTimer timer;
   int backoff = 0, skip = 0;
   void release() {
     if (!d_block && !h_mbox) return;
@@ -618,8 +619,10 @@ int channels_attempt(const ChannelsArgs &a, CWorkspace &ws, bool *retry_exact, b
     }
   }
   const auto t0 = std::chrono::steady_clock::now();
+  ws.timer.before(a.stream);
   hipLaunchKernelGGL((channels_fit_kernel<MODEL, FAST>), dim3(G), dim3(kRThreads), 0, a.stream, c);
   HIP_OK(hipGetLastError());
+  ws.timer.after(a.stream);
   {  // wait on the pinned mailboxes; the launch always terminates (bounded spins), which hipStreamQuery reports
     auto all_done = [&] {
       for (int k = 0; k < a.K; ++k)
@@ -667,6 +670,7 @@ int channels_attempt(const ChannelsArgs &a, CWorkspace &ws, bool *retry_exact, b
     ws.stats[k].jac_passes = mb.n_jac;
     ws.stats[k].eval_passes = mb.n_eval;
     ws.stats[k].device_us = (double)(mb.t_last - mb.t_first) / 100.0;
+    ws.stats[k].kernel_us = k == 0 ? ws.timer.elapsed_us() : ws.stats[0].kernel_us;  // (the shared launch's)
     for (int i = 0; i < 8; ++i) ws.stats[k].stamps[i] = mb.stamps[i];
     if (mb.ret < 0) worst = kLmError;
   }

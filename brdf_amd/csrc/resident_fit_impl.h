@@ -1115,6 +1115,7 @@ struct RWorkspace {
   long long h_trace[8 * (kRowStride + 1)] = {0};  // + one row: the sections of the LM step (LM_STAMP)
   unsigned tag_base = 0;
   FitStats stats{};
+  LaunchTimer timer;
   // After a launch that could not run co-resident (GPU shared with other kernels / ranks: every workgroup burns its
   // spin budget before the launch drains) the resident path steps aside for the next `skip` fits, doubling up to
   // 1024 while it keeps failing, instead of paying that budget on every fit.
@@ -1245,8 +1246,10 @@ int resident_attempt(const StreamFitArgs &a, RWorkspace &ws, bool *retry_exact, 
       return 0;
     }
   }
+  ws.timer.before(a.stream);
   hipLaunchKernelGGL((resident_fit_kernel<MODEL, METHOD, FAST, false>), dim3(G), dim3(kRThreads), 0, a.stream, c, BatchCtx{});
   HIP_OK(hipGetLastError());
+  ws.timer.after(a.stream);
   {  // wait on the pinned mailbox (a stream synchronise sleeps and wakes up tens of microseconds late); the launch
      // always terminates (bounded spins), which hipStreamQuery reports even if `done` never comes
     volatile int *done = &mb.done;
@@ -1287,6 +1290,7 @@ int resident_attempt(const StreamFitArgs &a, RWorkspace &ws, bool *retry_exact, 
   ws.stats.jac_passes = mb.n_jac;
   ws.stats.eval_passes = mb.n_eval;
   ws.stats.device_us = (double)(mb.t_last - mb.t_first) / 100.0;  // first pass start -> result (s_memrealtime, 100 MHz)
+  ws.stats.kernel_us = ws.timer.elapsed_us();
   for (int k = 0; k < 8; ++k) ws.stats.stamps[k] = mb.stamps[k];
   return mb.ret;
 }

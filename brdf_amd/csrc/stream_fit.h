@@ -78,9 +78,34 @@ struct FitStats {
   long long passes, jac_passes, eval_passes;
   long long launches;  // kernel launches enqueued for the fit, run-ahead launches that found it finished included
   double device_us;
+  double kernel_us;    // launch timing on (launch_timing_enabled()): HIP events recorded on the fit's stream right in front of and
+                       // right behind its resident launch -- the kernel's duration as the stream sees it; otherwise -1
   long long stamps[8];
 };
 FitStats stream_fit_last_stats();
+// brdf_hip_set_launch_timing(): the resident regimes bracket their launch with a HIP event pair on the launch stream (bench.py's
+// roofline reads it; off by default: two event records and one event wait per fit)
+bool launch_timing_enabled();
+void set_launch_timing(bool on);
+// an event pair per host thread, created on first use (resident_fit_impl.h / channels_fit_impl.h)
+struct LaunchTimer {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  bool armed = false;
+  void before(hipStream_t s) {
+    armed = false;
+    if (!launch_timing_enabled()) return;
+    if (!e0 && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) return;
+    armed = hipEventRecord(e0, s) == hipSuccess;
+  }
+  void after(hipStream_t s) {
+    if (armed) armed = hipEventRecord(e1, s) == hipSuccess;
+  }
+  double elapsed_us() {  // after the launch is known to have finished
+    float ms = 0.0f;
+    if (!armed || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return -1.0;
+    return 1e3 * (double)ms;
+  }
+};
 
 // resident single-launch regime (resident_fit.hip): true if it handled the fit
 bool resident_fit_try(const StreamFitArgs &a, int *ret);

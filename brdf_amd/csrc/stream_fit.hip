@@ -14,6 +14,7 @@
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -657,6 +658,7 @@ static int stream_fit_attempt(const StreamFitArgs &a, bool fast, bool *retry_exa
   ws.stats.jac_passes = mb.n_jac;
   ws.stats.eval_passes = mb.n_eval;
   ws.stats.device_us = (double)(mb.t_last - mb.t_first) / 100.0;  // s_memrealtime ticks at 100 MHz
+  ws.stats.kernel_us = -1.0;  // (a chain of launches with host decisions in between: timed by its callers' events)
   for (int k = 0; k < 8; ++k) ws.stats.stamps[k] = mb.stamps[k];
 #ifdef BRDF_STAMPS
   if (const char *path = getenv("BRDF_HIP_STEP_DUMP")) {  // diagnostic: per-pass cost of the LM step by transition
@@ -686,6 +688,10 @@ int pg_candidates() {
 
 // BRDF_HIP_DIF_CHAIN=k: dlevmar_dif trial points per sweep in a chain of rejections (lm_machine.h: DifMachine::Cold::multi;
 // default 8, 1 = one at a time)
+static std::atomic<int> g_launch_timing{0};
+bool launch_timing_enabled() { return g_launch_timing.load(std::memory_order_relaxed) != 0; }
+void set_launch_timing(bool on) { g_launch_timing.store(on ? 1 : 0, std::memory_order_relaxed); }
+
 int dif_chain_candidates() {
   const char *e = getenv("BRDF_HIP_DIF_CHAIN");
   const int k = e ? atoi(e) : kMaxCand;

@@ -120,7 +120,7 @@ def last_channels_stats(channels: int = 3):
         passes, jac, us = C.c_longlong(0), C.c_longlong(0), C.c_double(0.0)
         lib.brdf_hip_last_channels_stats(c, C.byref(shared), C.byref(passes), C.byref(jac), C.byref(us))
         per.append({"passes": passes.value, "jac_passes": jac.value, "device_us": us.value})
-    return {"shared_launch": bool(shared.value), "channels": per}
+    return {"shared_launch": bool(shared.value), "channels": per, "kernel_us": lib.brdf_hip_last_channels_kernel_us()}
 
 
 def fit_batch(method: int, model: int, angles, x, p0, *, lb=None, ub=None, itmax=100, opts=None):
@@ -337,4 +337,10 @@ def last_fit_stats() -> dict:
     us = C.c_double(0.0)
     lib.brdf_hip_last_fit_stats(C.byref(a), C.byref(b), C.byref(c), C.byref(us))
     return {"passes": a.value, "jac_passes": b.value, "eval_passes": c.value, "device_us": us.value,
-            "launches": lib.brdf_hip_last_fit_launches()}
+            "launches": lib.brdf_hip_last_fit_launches(), "kernel_us": lib.brdf_hip_last_fit_kernel_us()}
+
+
+def set_launch_timing(on: bool) -> None:
+    """resident fits bracket their launch with a HIP event pair on the launch stream; last_fit_stats()["kernel_us"] /
+    last_channels_stats()["kernel_us"] then hold the kernel's duration (-1 otherwise)"""
+    lib.brdf_hip_set_launch_timing(1 if on else 0)

@@ -258,6 +258,13 @@ int brdf_hip_last_fit_stats(long long *passes, long long *jac_passes, long long 
 /* kernel launches the most recent brdf_hip_fit_dev enqueued (its passes + the few run-ahead launches that found
  * the fit finished and returned at once): the population a profiler averages a kernel's duration over. */
 long long brdf_hip_last_fit_launches(void);
+/* Launch timing (off by default).  On: a resident fit (single or shared-channel launch) is bracketed by a HIP event pair recorded
+ * on the fit's own stream right in front of and right behind the kernel launch; after the call, the kernel's duration in
+ * microseconds as that stream saw it -- what rocprofv3 --kernel-trace reports for the same launch, plus the two event packets.
+ * -1 when timing is off or the last fit ran as a chain of launches.  bench.py's roofline uses it. */
+void brdf_hip_set_launch_timing(int on);
+double brdf_hip_last_fit_kernel_us(void);
+double brdf_hip_last_channels_kernel_us(void);
 
 /* only meaningful in diagnostic builds (-DBRDF_STAMPS): shader cycles spent per section of the pass
  * kernel (launch chain: load state, fold, step, uniforms, persist, sweep, reduce; resident regime: -, sweep +
