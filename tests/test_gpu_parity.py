@@ -598,6 +598,33 @@ def test_resident_and_launch_chain_regimes(gpu, monkeypatch):
                 assert (st["launches"] == 1) == (env == "1"), st
 
 
+def test_launch_timing_brackets_the_resident_launch(gpu):
+    """brdf_hip_set_launch_timing: the event pair the library records on the fit's stream around its resident launch.  The kernel's
+    duration contains the device clock from the first pass to the result (the launch's prologue comes on top) and is not far
+    above it; off, or for a fit that runs as a chain of launches, the figure is -1; the fit itself does not change."""
+    torch, brdf_amd, dev = gpu
+    angles, x, _ = synth.make_single(2, 200_000)
+    try:
+        brdf_amd.set_launch_timing(False)
+        plain = _dev_fit(gpu, 1, 2, angles, x)
+        assert brdf_amd.last_fit_stats()["kernel_us"] == -1.0
+        brdf_amd.set_launch_timing(True)
+        for method in (0, 1):
+            _dev_fit(gpu, method, 2, angles, x)  # (first use creates the events)
+            timed = _dev_fit(gpu, method, 2, angles, x)
+            st = brdf_amd.last_fit_stats()
+            assert st["launches"] == 1
+            assert 0.0 < st["device_us"] <= st["kernel_us"] <= st["device_us"] + 200.0, st
+        assert timed.ret == plain.ret and np.array_equal(timed.p, plain.p) and np.array_equal(timed.info, plain.info)
+        xs = _channel_measurements(2, angles, 200_000)
+        a = torch.from_numpy(np.ascontiguousarray(angles)).to(dev)
+        brdf_amd.fit_channels(1, 2, a, torch.from_numpy(xs).to(dev), synth.P0[2], lb=synth.LB, ub=synth.UB, itmax=synth.ITMAX, opts=synth.OPTS)
+        st = brdf_amd.last_channels_stats(3)
+        assert st["shared_launch"] and max(c["device_us"] for c in st["channels"]) <= st["kernel_us"] <= max(c["device_us"] for c in st["channels"]) + 200.0, st
+    finally:
+        brdf_amd.set_launch_timing(False)
+
+
 @pytest.mark.parametrize("method,n,models", [(0, 262145, (2, 1)), (1, 262145, (2, 1)), (2, 262145, (2,)), (3, 262145, (2,)),
                                              (0, 263000, (2, 1)), (1, 263000, (2,)), (2, 263000, (2,)), (3, 263000, (2,)),
                                              (0, 523009, (2,)), (1, 523009, (2,))])
