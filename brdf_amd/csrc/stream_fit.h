@@ -90,11 +90,27 @@ void set_launch_timing(bool on);
 // an event pair per host thread, created on first use (resident_fit_impl.h / channels_fit_impl.h)
 struct LaunchTimer {
   hipEvent_t e0 = nullptr, e1 = nullptr;
+  int device = -1;  // the events belong to the device they were created on
   bool armed = false;
+  void drop() {
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    e0 = e1 = nullptr;
+  }
+  ~LaunchTimer() { drop(); }
   void before(hipStream_t s) {
     armed = false;
     if (!launch_timing_enabled()) return;
-    if (!e0 && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) return;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    if (dev != device) {
+      drop();
+      device = dev;
+    }
+    if (!e0 && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) {
+      drop();
+      return;
+    }
     armed = hipEventRecord(e0, s) == hipSuccess;
   }
   void after(hipStream_t s) {
