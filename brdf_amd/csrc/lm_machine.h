@@ -356,13 +356,20 @@ struct DifMachine {
     Real info[kInfoSz], covar[M * M];
     int ret;
   };
-  struct Core {  // everything an LM step reads or writes, except the request it leaves
+  // Everything an LM step reads or writes, except the request it leaves: the counters and flags, and the reals.  run() takes the
+  // two halves separately, so that a kernel that steps ONE machine with a whole wave can keep the counters in scalar registers for
+  // the whole fit (resident_fit_impl.h: every `if (h.k < c.itmax ...)` on an LDS-resident machine is a dependent ds_read ->
+  // s_waitcnt -> compare -> branch) while the reals stay where the machine lives.
+  struct CoreInts {
     int phase, k, stop, nu, nfev, njap, nlss, updjac, updp, newjac;
     int sel_hx, sel_j, accepted;
     int chain, single, mcnt;  // multi: rejections without an update in a row; next solve issues a plain trial; candidates out
+  };
+  struct CoreReals {
     Real p[M], mu, p_e2, jte_inf, p_l2, dp_l2, pdp_e2;
     Real jtj[M * M], jte[M], dp[M];
   };
+  struct Core : CoreInts, CoreReals {};
   struct Cool {  // the less busy half of the state (see Hot)
     Real init_e2, diag[M], pdp[M];
     Real spec_jtj[M * M], spec_jte[M];  // normal equations of the Broyden-updated J, adopted lazily
@@ -377,7 +384,7 @@ struct DifMachine {
   };
   // where ONE machine is stepped by a whole wave (every lane the same values): moves the counters and flags of a
   // register copy into scalar registers, so that the step's integer logic and branches run on the scalar unit
-  static LM_HD void uniform_ints(Core &h) {
+  static LM_HD void uniform_ints(CoreInts &h) {
     h.phase = lm_uniform(h.phase);
     h.k = lm_uniform(h.k);
     h.stop = lm_uniform(h.stop);
@@ -440,7 +447,7 @@ struct DifMachine {
     h.phase = D_INIT_EVAL;
   }
 
-  static LM_HD void clear_req(const Core &h, Request<M, Real> &req) {
+  static LM_HD void clear_req(const CoreInts &h, Request<M, Real> &req) {
     req.kind = RQ_DONE;
     req.central = 0;
     req.sel_hx = h.sel_hx;
@@ -452,7 +459,7 @@ struct DifMachine {
     for (int i = 0; i < M; ++i) req.p[i] = req.d[i] = req.q[i] = req.dp[i] = Real(0.0);
   }
 
-  static LM_HD void gradient_stats(Core &h, Cool &cool) {  // lm_core.c:657-662
+  static LM_HD void gradient_stats(CoreReals &h, Cool &cool) {  // lm_core.c:657-662
     h.p_l2 = h.jte_inf = Real(0.0);
     for (int i = 0; i < M; ++i) {
       const Real t = lm_abs(h.jte[i]);
@@ -468,22 +475,26 @@ struct DifMachine {
   LM_HD void step(const Real *s, Real maxabs) { run<ONE_LANE, MULTI>(c, h, h.cool, h.req, s, maxabs); }
 
   template <bool ONE_LANE, bool MULTI = false>
-  static LM_HD void run(Cold &c, Core &h, Cool &cool, Request<M, Real> &req, const Real *s, Real /*maxabs*/) {
-    int ph = ONE_LANE ? lm_uniform(h.phase) : h.phase;  // scalar register: phase transitions become scalar jumps
+  static LM_HD void run(Cold &c, Core &h, Cool &cool, Request<M, Real> &req, const Real *s, Real maxabs) {
+    run<ONE_LANE, MULTI>(c, static_cast<CoreInts &>(h), static_cast<CoreReals &>(h), cool, req, s, maxabs);
+  }
+  template <bool ONE_LANE, bool MULTI = false>
+  static LM_HD void run(Cold &c, CoreInts &hi, CoreReals &h, Cool &cool, Request<M, Real> &req, const Real *s, Real /*maxabs*/) {
+    int ph = ONE_LANE ? lm_uniform(hi.phase) : hi.phase;  // scalar register: phase transitions become scalar jumps
     LM_STAMP(0);
     for (;;) {
       if (ONE_LANE) ph = lm_uniform(ph);  // re-assert uniformity: assignments under (formally) divergent branches lose it
       // (an ordered chain of guarded blocks, not a switch: see BcMachine::run)
       if (ph <= 0 || ph >= D_DONE) {
         req.kind = RQ_DONE;
-        { h.phase = ph; return; }
+        { hi.phase = ph; return; }
       }
       LM_PHASE(D_INIT_EVAL) {  // lm_core.c:551-564
-        h.nfev = 1;
+        hi.nfev = 1;
         h.p_e2 = s[0];
         cool.init_e2 = h.p_e2;
-        if (!lm_finite(h.p_e2)) h.stop = 7;
-        h.nu = 20;
+        if (!lm_finite(h.p_e2)) hi.stop = 7;
+        hi.nu = 20;
         ph = D_ITER_TOP;
         break;
       } LM_PHASE_END
@@ -491,7 +502,7 @@ struct DifMachine {
       LM_PHASE(D_AFTER_JAC) {
         unpack_lower<M>(s, h.jtj);
         for (int i = 0; i < M; ++i) h.jte[i] = s[SumLayout<M>::NL + i];
-        h.newjac = 0;
+        hi.newjac = 0;
         gradient_stats(h, cool);
         ph = D_SOLVE;
         break;
@@ -500,35 +511,35 @@ struct DifMachine {
       LM_PHASE(D_AFTER_TRIAL) {  // lm_core.c:742-790
         h.pdp_e2 = s[0];
         if (!lm_finite(h.pdp_e2)) {
-          h.stop = 7;
+          hi.stop = 7;
           ph = D_FINISH;
           break;
         }
         const Real dF = h.p_e2 - h.pdp_e2;
-        const bool updated = (h.updp || dF > 0);
-        if (MULTI) h.chain = updated ? 0 : h.chain + 1;  // (not updated => dF <= 0 => rejected below)
+        const bool updated = (hi.updp || dF > 0);
+        if (MULTI) hi.chain = updated ? 0 : hi.chain + 1;  // (not updated => dF <= 0 => rejected below)
         Real dL = Real(0.0);
         for (int i = 0; i < M; ++i) dL += h.dp[i] * (h.mu * h.dp[i] + h.jte[i]);
-        h.accepted = (dL > Real(0.0) && dF > Real(0.0)) ? 1 : 0;
-        if (h.accepted) {  // damping update uses dF, dL of this step: do it now, they are not kept
+        hi.accepted = (dL > Real(0.0) && dF > Real(0.0)) ? 1 : 0;
+        if (hi.accepted) {  // damping update uses dF, dL of this step: do it now, they are not kept
           Real t = (Real(2.0) * dF / dL - Real(1.0));
           t = Real(1.0) - t * t * t;
           h.mu = h.mu * ((t >= Real(kOneThird)) ? t : Real(kOneThird));
         }
         if (updated) {
-          ++h.updjac;
-          h.newjac = 1;
+          ++hi.updjac;
+          hi.newjac = 1;
           if (c.speculative) {  // adopt the speculatively updated Jacobian; keep its products, paired with the
                                 // residual that stays live -- they replace jtj/jte at the top of the next
                                 // iteration, as in the reference
-            h.sel_j ^= 1;
+            hi.sel_j ^= 1;
             unpack_lower<M>(s + 1, cool.spec_jtj);
-            const Real *g = s + 1 + SumLayout<M>::NL + (h.accepted ? 0 : M);
+            const Real *g = s + 1 + SumLayout<M>::NL + (hi.accepted ? 0 : M);
             for (int i = 0; i < M; ++i) cool.spec_jte[i] = g[i];
           } else {
-            clear_req(h, req);
+            clear_req(hi, req);
             req.kind = RQ_DIF_UPDATE;
-            req.aux = h.accepted;
+            req.aux = hi.accepted;
             for (int i = 0; i < M; ++i) {
               req.p[i] = h.p[i];
               req.q[i] = cool.pdp[i];
@@ -536,7 +547,7 @@ struct DifMachine {
             }
             req.dp_l2 = h.dp_l2;
             ph = D_AFTER_UPDATE;
-            { h.phase = ph; return; }
+            { hi.phase = ph; return; }
           }
         }
         LM_STAMP(1);
@@ -554,47 +565,47 @@ struct DifMachine {
       if constexpr (MULTI)
       LM_PHASE(D_AFTER_MULTI) {  // judge the candidates of one sweep in the reference's order: each is one iteration of
                                  // lm_core.c:566-807 that ends in the rejection branch without a Broyden update
-        const int cnt = h.mcnt;
+        const int cnt = hi.mcnt;
         int next = D_ITER_TOP;
         for (int j = 0; j < kMaxCand; ++j) {
-          if (j >= cnt || !(h.k < c.itmax)) break;  // (the iteration count ends the loop at its top, lm_core.c:566)
+          if (j >= cnt || !(hi.k < c.itmax)) break;  // (the iteration count ends the loop at its top, lm_core.c:566)
           const Real e2 = s[j];
           if (lm_finite(e2) && h.p_e2 - e2 > Real(0.0)) {  // dF > 0: Broyden update, maybe an accepted step -- the plain
-            h.single = 1;                                   // trial pass evaluates this candidate again and forms its sums
+            hi.single = 1;                                   // trial pass evaluates this candidate again and forms its sums
             break;
           }
-          ++h.nlss;  // the solve that produced this candidate (lm_core.c:691) ...
-          ++h.nfev;  // ... and its evaluation (lm_core.c:738)
+          ++hi.nlss;  // the solve that produced this candidate (lm_core.c:691) ...
+          ++hi.nfev;  // ... and its evaluation (lm_core.c:738)
           h.pdp_e2 = e2;
           h.dp_l2 = cool.ml2[j];
           if (!lm_finite(e2)) {  // lm_core.c:749
-            h.stop = 7;
+            hi.stop = 7;
             next = D_FINISH;
             break;
           }
-          ++h.chain;
-          h.mu *= h.nu;  // lm_core.c:797-806
-          const int nu2 = (int)((unsigned)h.nu << 1);
-          if (nu2 <= h.nu) {
-            h.stop = 5;
+          ++hi.chain;
+          h.mu *= hi.nu;  // lm_core.c:797-806
+          const int nu2 = (int)((unsigned)hi.nu << 1);
+          if (nu2 <= hi.nu) {
+            hi.stop = 5;
             next = D_FINISH;
             break;
           }
-          h.nu = nu2;
-          ++h.k;
+          hi.nu = nu2;
+          ++hi.k;
         }
         ph = next;
         break;
       } LM_PHASE_END
 
       LM_PHASE(D_DECIDE) {
-        if (h.accepted) {
-          h.nu = 2;
+        if (hi.accepted) {
+          hi.nu = 2;
           for (int i = 0; i < M; ++i) h.p[i] = cool.pdp[i];
-          if (c.speculative) h.sel_hx ^= 1;  // e, hx <- trial values
+          if (c.speculative) hi.sel_hx ^= 1;  // e, hx <- trial values
           h.p_e2 = h.pdp_e2;
-          h.updp = 1;
-          ++h.k;
+          hi.updp = 1;
+          ++hi.k;
           ph = D_ITER_TOP;
           break;
         }
@@ -603,45 +614,45 @@ struct DifMachine {
       } LM_PHASE_END
 
       LM_PHASE(D_REJECT) {  // lm_core.c:797-806
-        h.mu *= h.nu;
-        const int nu2 = (int)((unsigned)h.nu << 1);
-        if (nu2 <= h.nu) {
-          h.stop = 5;
+        h.mu *= hi.nu;
+        const int nu2 = (int)((unsigned)hi.nu << 1);
+        if (nu2 <= hi.nu) {
+          hi.stop = 5;
           ph = D_FINISH;
           break;
         }
-        h.nu = nu2;
+        hi.nu = nu2;
         for (int i = 0; i < M; ++i) h.jtj[i * M + i] = cool.diag[i];
-        ++h.k;
+        ++hi.k;
         ph = D_ITER_TOP;
         break;
       } LM_PHASE_END
 
       LM_PHASE(D_ITER_TOP) {
-        if (!(h.k < c.itmax && !h.stop)) {
+        if (!(hi.k < c.itmax && !hi.stop)) {
           ph = D_FINISH;
           break;
         }
         if (h.p_e2 <= c.o.eps3) {
-          h.stop = 6;
+          hi.stop = 6;
           ph = D_FINISH;
           break;
         }
-        if ((h.updp && h.nu > 16) || h.updjac == c.refresh) {  // fresh FD Jacobian, lm_core.c:578-588
-          clear_req(h, req);
+        if ((hi.updp && hi.nu > 16) || hi.updjac == c.refresh) {  // fresh FD Jacobian, lm_core.c:578-588
+          clear_req(hi, req);
           req.kind = RQ_DIF_JAC;
           req.central = !c.o.forward;
           for (int i = 0; i < M; ++i) req.p[i] = h.p[i];
           fd_steps<M>(h.p, c.o.delta, req.d);
-          ++h.njap;
-          h.nfev += c.o.forward ? M : 2 * M;
-          h.nu = 2;
-          h.updjac = 0;
-          h.updp = 0;
-          h.newjac = 1;
-          if (MULTI) h.chain = 0;
+          ++hi.njap;
+          hi.nfev += c.o.forward ? M : 2 * M;
+          hi.nu = 2;
+          hi.updjac = 0;
+          hi.updp = 0;
+          hi.newjac = 1;
+          if (MULTI) hi.chain = 0;
           ph = D_AFTER_JAC;
-          { h.phase = ph; return; }
+          { hi.phase = ph; return; }
         }
         ph = D_GRADIENT;
         break;
@@ -649,8 +660,8 @@ struct DifMachine {
 
       LM_PHASE(D_GRADIENT) {
         LM_STAMP(5);
-        if (h.newjac) {  // lm_core.c:590-664 with the sums the trial pass produced for the updated J
-          h.newjac = 0;
+        if (hi.newjac) {  // lm_core.c:590-664 with the sums the trial pass produced for the updated J
+          hi.newjac = 0;
           for (int i = 0; i < M * M; ++i) h.jtj[i] = cool.spec_jtj[i];
           for (int i = 0; i < M; ++i) h.jte[i] = cool.spec_jte[i];
           gradient_stats(h, cool);
@@ -663,17 +674,17 @@ struct DifMachine {
         LM_STAMP(2);
         if (h.jte_inf <= c.o.eps1) {  // lm_core.c:676-680
           h.dp_l2 = Real(0.0);
-          h.stop = 1;
+          hi.stop = 1;
           ph = D_FINISH;
           break;
         }
-        if (h.k == 0) {  // lm_core.c:683-687
+        if (hi.k == 0) {  // lm_core.c:683-687
           Real t = -LmLimits<Real>::max();
           for (int i = 0; i < M; ++i)
             if (cool.diag[i] > t) t = cool.diag[i];
           h.mu = c.o.tau * t;
         }
-        if (MULTI && c.multi > 1 && h.updp == 0 && h.chain >= 1 && !h.single) {
+        if (MULTI && c.multi > 1 && hi.updp == 0 && hi.chain >= 1 && !hi.single) {
           // no step taken since the fresh Jacobian and the last trial was rejected without an update: if this trial is
           // rejected too, the next one differs by its damping only.  Form the trial points of the next rejections as the
           // loop would (same solves, same tests), stop in front of the first one the loop would not evaluate.
@@ -684,7 +695,7 @@ struct DifMachine {
             pc[i] = h.p[i];
           }
           Real mu = h.mu;
-          int nu = h.nu, kk = h.k, cnt = 0;
+          int nu = hi.nu, kk = hi.k, cnt = 0;
           const Real pl2 = h.p_l2;
 #if defined(__HIP_DEVICE_COMPILE__)
           if (ONE_LANE) {
@@ -742,19 +753,19 @@ struct DifMachine {
             ++kk;
           }
           if (cnt >= 2) {
-            h.mcnt = cnt;
+            hi.mcnt = cnt;
             req.kind = RQ_EVAL_MULTI;
             req.nk = cnt;
             req.scal = Real(1.0);
             ph = D_AFTER_MULTI;
-            { h.phase = ph; return; }
+            { hi.phase = ph; return; }
           }
         }
-        if (MULTI) h.single = 0;
+        if (MULTI) hi.single = 0;
         for (int i = 0; i < M; ++i) h.jtj[i * M + i] += h.mu;
         const int solved = lu_solve<M>(h.jtj, h.jte, h.dp);
         LM_STAMP(3);
-        ++h.nlss;
+        ++hi.nlss;
         if (!solved) {
           ph = D_REJECT;
           break;
@@ -766,16 +777,16 @@ struct DifMachine {
           h.dp_l2 += t * t;
         }
         if (h.dp_l2 <= c.o.eps2sq * h.p_l2) {
-          h.stop = 2;
+          hi.stop = 2;
           ph = D_FINISH;
           break;
         }
         if (h.dp_l2 >= (h.p_l2 + c.o.eps2) / (Real(kEpsilon) * Real(kEpsilon))) {
-          h.stop = 4;
+          hi.stop = 4;
           ph = D_FINISH;
           break;
         }
-        clear_req(h, req);
+        clear_req(hi, req);
         req.kind = RQ_DIF_TRIAL;
         for (int i = 0; i < M; ++i) {
           req.p[i] = h.p[i];
@@ -783,14 +794,14 @@ struct DifMachine {
           req.dp[i] = h.dp[i];
         }
         req.dp_l2 = h.dp_l2;
-        ++h.nfev;
+        ++hi.nfev;
         ph = D_AFTER_TRIAL;
         LM_STAMP(4);
-        { h.phase = ph; return; }
+        { hi.phase = ph; return; }
       } LM_PHASE_END
 
       LM_PHASE(D_FINISH) {  // lm_core.c:809-841
-        if (h.k >= c.itmax) h.stop = 3;
+        if (hi.k >= c.itmax) hi.stop = 3;
         for (int i = 0; i < M; ++i) h.jtj[i * M + i] = cool.diag[i];
         c.info[0] = cool.init_e2;
         c.info[1] = h.p_e2;
@@ -800,16 +811,16 @@ struct DifMachine {
         for (int i = 0; i < M; ++i)
           if (t < h.jtj[i * M + i]) t = h.jtj[i * M + i];
         c.info[4] = h.mu / t;
-        c.info[5] = (Real)h.k;
-        c.info[6] = (Real)h.stop;
-        c.info[7] = (Real)h.nfev;
-        c.info[8] = (Real)h.njap;
-        c.info[9] = (Real)h.nlss;
+        c.info[5] = (Real)hi.k;
+        c.info[6] = (Real)hi.stop;
+        c.info[7] = (Real)hi.nfev;
+        c.info[8] = (Real)hi.njap;
+        c.info[9] = (Real)hi.nlss;
         if (c.want_covar) lu_covar<M>(h.jtj, c.covar, h.p_e2, c.n);
-        c.ret = (h.stop != 4 && h.stop != 7) ? h.k : kLmError;
-        clear_req(h, req);
+        c.ret = (hi.stop != 4 && hi.stop != 7) ? hi.k : kLmError;
+        clear_req(hi, req);
         ph = D_DONE;
-        { h.phase = ph; return; }
+        { hi.phase = ph; return; }
       } LM_PHASE_END
     }
   }

@@ -909,6 +909,31 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
 #endif
     typename Machine::Core hcore = sm.h;
     if constexpr (kCoreInRegs) Machine::uniform_ints(hcore);
+    // dlevmar_dif: what the step reads in every pass but never (constants: options, limits) or only itself (its counters and
+    // flags) changes lives in SCALAR registers for the whole fit; the reals stay in LDS with the rest of the machine.  On an
+    // LDS-resident machine every `if (h.k < c.itmax ...)` is a dependent ds_read -> s_waitcnt -> compare -> branch.  Same box,
+    // 10^6-sample fits: Ward 403.2 -> 401.9 us (constants) -> 398.8 us (+ counters), Blinn-Phong 342.9 -> 338.2 us; all of
+    // Machine::Core in (vector) registers was slower (BRDF_CORE_IN_REGS above), the integers alone cost no vector register.
+    typename Machine::Cold cold0;
+    typename std::conditional<METHOD == 0, typename DifMachine<kM>::CoreInts, int>::type ints_regs{};
+    if constexpr (METHOD == 0) {
+      cold0.itmax = lm_uniform(sm.c.itmax);
+      cold0.n = lm_uniform(sm.c.n);
+      cold0.want_covar = lm_uniform(sm.c.want_covar);
+      cold0.refresh = lm_uniform(sm.c.refresh);
+      cold0.speculative = lm_uniform(sm.c.speculative);
+      cold0.multi = lm_uniform(sm.c.multi);
+      cold0.o.forward = lm_uniform(sm.c.o.forward);
+      cold0.o.tau = scalar_copy(sm.c.o.tau);
+      cold0.o.eps1 = scalar_copy(sm.c.o.eps1);
+      cold0.o.eps2 = scalar_copy(sm.c.o.eps2);
+      cold0.o.eps2sq = scalar_copy(sm.c.o.eps2sq);
+      cold0.o.eps3 = scalar_copy(sm.c.o.eps3);
+      cold0.o.delta = scalar_copy(sm.c.o.delta);
+      ints_regs = sm.h;
+      Machine::uniform_ints(ints_regs);
+    }
+    (void)cold0, (void)ints_regs;
     const long long t_first = (long long)wall_clock64();
     unsigned epoch = 0;
     for (;; ++epoch) {
@@ -1010,9 +1035,22 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
         else
           Machine::template run<true>(sm.c, hcore, sm.h.req, sums, sums[kSums]);
       } else {
-        if constexpr (METHOD == 0)
-          sm.template step<true, true>(sums, sums[kSums]);  // (+ chains of rejections, several trial points to a sweep)
-        else if constexpr (METHOD == 1)
+        if constexpr (METHOD == 0) {  // (+ chains of rejections, several trial points to a sweep)
+          typename Machine::Cold cc;  // (results are written by the finishing step only and stored right behind it: nothing carried)
+          cc.itmax = cold0.itmax, cc.n = cold0.n, cc.want_covar = cold0.want_covar, cc.refresh = cold0.refresh;
+          cc.speculative = cold0.speculative, cc.multi = cold0.multi, cc.o = cold0.o;
+          for (int i = 0; i < kInfoSz; ++i) cc.info[i] = 0.0;
+          for (int i = 0; i < kM * kM; ++i) cc.covar[i] = 0.0;
+          cc.ret = kLmError;
+          Machine::template run<true, true>(cc, ints_regs, static_cast<typename Machine::CoreReals &>(sm.h), sm.h.cool, sm.h.req, sums, sums[kSums]);
+          Machine::uniform_ints(ints_regs);  // (assignments under formally divergent branches lose their uniformity: re-assert it)
+          if (sm.h.req.kind == RQ_DONE) {
+            for (int i = 0; i < kInfoSz; ++i) sm.c.info[i] = cc.info[i];
+            for (int i = 0; i < kM * kM; ++i) sm.c.covar[i] = cc.covar[i];
+            sm.c.ret = cc.ret;
+          }
+        } else
+        if constexpr (METHOD == 1)
           sm.template step<true, true, false, !BATCHED>(sums, sums[kSums]);  // (+ candidates evaluated by Jacobian passes: single fits only)
         else
           sm.template step<true>(sums, sums[kSums]);
