@@ -420,6 +420,67 @@ __device__ __forceinline__ bool control_exchange(const Ctx &ctx, unsigned epoch,
   return true;
 }
 
+// ---- the uniforms of a request, built by the control wave --------------------------------------------------------------------
+// PassUniforms::build() forms them one after the other on one lane's worth of values (every lane the same); each lin() / nl()
+// hides an fp64 division or two, and a finite-difference Jacobian request needs seven parameter sets (p, p + d_j e_j, p - d_j e_j),
+// a multi-candidate request up to eight: 2,500 shader-clock ticks of the 12 us a dlevmar_bc_dif pass takes.  Here lane l of the
+// wave forms parameter set l -- the same operations on the same operands as build(), hence the same bits -- and stores its
+// results where build() would.  Everything else goes to build().
+template <int MODEL>
+__device__ __forceinline__ void build_uniforms_wave(PassUniforms<MODEL> &u, const Request<kM> &r, bool need_base, bool analytic_jac) {
+  using Mdl = BrdfModel<MODEL>;
+  const int lane = (int)(threadIdx.x & (kWave - 1));
+  if (r.kind == RQ_EVAL_MULTI) {
+    u.ncand = r.nk;
+    u.analytic = analytic_jac ? 1 : 0;
+    if (lane < kMaxCand && lane < r.nk) {
+      const double pk[kM] = {r.pk[lane][0], r.pk[lane][1], r.pk[lane][2]};
+      u.lk[lane] = Mdl::lin(pk);
+      u.nk[lane] = Mdl::nl(pk);
+    }
+    return;
+  }
+  if ((r.kind == RQ_JAC && !analytic_jac) || r.kind == RQ_DIF_JAC) {
+    u.ncand = 0;
+    u.analytic = 0;
+    u.central = r.central;
+    u.scal = r.scal;
+    u.dp_l2 = r.dp_l2;
+#pragma unroll
+    for (int j = 0; j < kM; ++j) u.dp[j] = r.dp[j];
+    if (lane < 1 + 2 * kM) {  // 0: p;  1..3: p + d_j e_j;  4..6: p - d_j e_j
+      const int j = lane == 0 ? 0 : (lane - 1) % kM;
+      const bool plus = lane >= 1 && lane <= kM, minus = lane > kM;
+      double pp[kM];
+#pragma unroll
+      for (int i = 0; i < kM; ++i) {
+        pp[i] = r.p[i];
+        if (i == j && plus) pp[i] = r.p[i] + r.d[i];   // "p[j]+=d", misc_core.c:161 / "tmp+d", :202
+        if (i == j && minus) pp[i] = r.p[i] - r.d[i];  // "p[j]-=d", misc_core.c:199
+      }
+      const Lin l = Mdl::lin(pp);
+      const Nl nn = Mdl::nl(pp);
+      if (lane == 0) {
+        u.l0 = l;
+        u.n0 = nn;
+      } else if (plus) {
+        u.lp[j] = l;
+        if (j == kM - 1) u.np2 = nn;
+        double dj = r.d[0];
+#pragma unroll
+        for (int i = 1; i < kM; ++i)
+          if (i == j) dj = r.d[i];
+        u.dinv[j] = (r.central ? 0.5 : 1.0) / dj;
+      } else {
+        u.lm[j] = l;
+        if (j == kM - 1) u.nm2 = nn;
+      }
+    }
+    return;
+  }
+  u.build(r, need_base, analytic_jac);
+}
+
 // ---- one pass over a lane's samples ------------------------------------------------------------------------------
 // Executed by all eight waves: waves 1..7 on RegSamples (unrolled), the control wave on LdsSamples (rolled).  Leaves the
 // lane's partial sums in acc[] / mx and returns the number of sum slots of the request kind (a wave-uniform value).
@@ -1057,7 +1118,11 @@ __global__ __launch_bounds__(kRThreads) void resident_fit_kernel(ResidentCtx ctx
       }
       RSTAMP(7);  // the step alone
       if (sm.h.req.kind != RQ_DONE) {
-        if constexpr (METHOD == 1)
+        // (lane-parallel for the single box-constrained fit only: the dif kernels have no register for it -- 5 -> 10 spilled VGPRs --
+        // and hardly a request that gains; the batched bc kernel spills 8 with it)
+        if constexpr (METHOD == 1 && !BATCHED)
+          build_uniforms_wave(su, sm.h.req, /*need_base=*/false, sm.c.analytic_jac != 0);
+        else if constexpr (METHOD == 1)
           su.build(sm.h.req, /*need_base=*/false, sm.c.analytic_jac != 0);
         else
           su.build(sm.h.req, /*need_base=*/false, METHOD == 2);
